@@ -1,0 +1,163 @@
+/* yolov3_amd.h -- C-ABI of the MI355X-native (gfx950) kernels behind the YOLOv3 training hot path.
+ *
+ * The reference (zheng-yuwei/YOLOv3-tensorflow) has no FFI layer of its own: its hot path is reached through Python
+ * module surfaces and executed by TensorFlow built-in ops.  Each entry point below replaces the
+ * TensorFlow op(s) instantiated at the cited reference call site; the Python facades in yolov3_tensorflow_amd/ bind
+ * them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated, freed or synchronised here;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it, so every call is
+ *     capturable into a hipGraph;
+ *   - activations are NHWC bf16 (uint16 storage); logits, statistics, master weights and gradients are float32;
+ *   - conv weights (bf16 compute copies): forward/wgrad layout [Cout][R][S][Cin], dgrad layout [Cin][R][S][Cout] with the
+ *     taps flipped (made by yolo_repack_dgrad_weights);
+ *   - return value: 0 (YOLO_OK) on success, YOLO_ERR_INVALID_ARG (<0) for a rejected argument, or a positive
+ *     hipError_t; yolo_last_error() returns a thread-local message for the last non-zero status.
+ */
+#ifndef YOLOV3_AMD_H_
+#define YOLOV3_AMD_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YOLO_OK 0
+#define YOLO_ERR_INVALID_ARG (-1)
+#define YOLO_ABI_VERSION 1
+
+int yolo_abi_version(void);
+const char* yolo_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA (v_mfma_f32_16x16x32_bf16), NHWC.
+ * Replaces keras.layers.Conv2D at /root/reference/backbone/basic_backbone.py:42 (all backbone/neck convs) and
+ * /root/reference/yolov3/yolov3_detector.py:98-100,123-125,148-150 (detection convs, bias, float32 logits), plus the
+ * TF autodiff gradients of those ops.  UpSampling2D + concatenate (yolov3_detector.py:115-116,140-141) is folded into
+ * the operand gather of the following 1x1 convolution (C0 > 0).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t N, H, W;     /* input batch and spatial size */
+  int32_t Cin;         /* input channels, multiple of 8 and (Cin/8) a power of two (the RGB stem is padded 3 -> 8) */
+  int32_t C0;          /* > 0: the input is concat(upsample2x(src0[N,H/2,W/2,C0]), src1[N,H,W,Cin-C0]); 0: src1 only */
+  int32_t Cout;        /* output channels, padded to a multiple of 64 (255 -> 256, 170 -> 192) */
+  int32_t R, S;        /* kernel height / width */
+  int32_t stride;      /* 1 or 2 (same in both directions) */
+  int32_t pad_t, pad_l;/* top/left zero padding (TF 'same': (0,0) for k=3 s=2 on even sizes, (1,1) for k=3 s=1) */
+  int32_t Ho, Wo;      /* output spatial size */
+} yolo_conv_problem;
+
+/* y[N,Ho,Wo,Cout] = conv(x, w) (+ bias).  y is bf16 unless y_is_f32.  If stat_sum/stat_sq are non-NULL the kernel also
+ * writes per-channel partial sums / sums of squares of the bf16-rounded outputs: arrays [stat_rows][Cout] where
+ * stat_rows = yolo_conv2d_stat_rows(p) (reduced later by yolo_bn_finalize). */
+int yolo_conv2d_stat_rows(const yolo_conv_problem* p);
+int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd, const float* bias,
+                    void* y, int y_is_f32, float* stat_sum, float* stat_sq, void* stream);
+/* dx[N,H,W,Cin] (=|+=) conv_transpose(dy[N,Ho,Wo,Cout], w).  Cin must be a multiple of 64.  accumulate != 0 adds into dx. */
+int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                      void* stream);
+/* dw[Cout][R][S][Cin] += x^T * dy (float32 atomics; the caller zeroes dw once per step).  split_k <= 0 = auto. */
+int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
+                      int split_k, void* stream);
+/* bf16 [Cout][R][S][Cin] -> bf16 [Cin][R][S][Cout] with flipped taps (operand layout of yolo_conv2d_dgrad). */
+int yolo_repack_dgrad_weights(const void* w_fwd, void* w_dgrad, int Cout, int R, int S, int Cin, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * BatchNorm (training mode) + ReLU + residual add, stem BN -> max-pool -> ReLU, and their backward passes.
+ * Replace keras BatchNormalization (/root/reference/backbone/basic_backbone.py:75-77, momentum .9, eps 1e-5),
+ * Activation('relu') (:89), layers.add (:124), MaxPooling2D(3, 2, 'same') (/root/reference/backbone/resnet18.py:60) and
+ * their TF autodiff.  Tensors are bf16 [M][C] (M = N*H*W), C/8 a power of two <= 256; per-channel vectors are float32.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* number of partial rows the reduction kernels (yolo_bn_stats, *_bwd_reduce) write for an [M][C] tensor */
+int yolo_reduce_rows(int M, int C);
+/* partial[rows][2][C] = per-workgroup (sum x, sum x^2) of x[M][C]; for BatchNorms whose input is not a conv output */
+int yolo_bn_stats(const void* x, int M, int C, float* partial, void* stream);
+/* reduce P partial rows (row stride in floats) -> mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; update the
+ * moving statistics (NULL = skip).  gamma/beta NULL = 1/0. */
+int yolo_bn_finalize(const float* psum, const float* psq, int P, int64_t row_stride, int C, float count, const float* gamma,
+                     const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* scale,
+                     float* shift, float* mean, float* rstd, void* stream);
+/* out = act(y*scale + shift + T); T = 0 (res NULL), res (res_scale NULL) or res*res_scale + res_shift; scale NULL = identity */
+int yolo_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+                    const float* res_shift, void* out, int64_t M, int C, int relu, void* stream);
+/* out[N,Ho,Wo,C] = act(maxpool3x3s2(y*scale + shift)); argmax[N,Ho,Wo,C] = window position 0..8 of the first maximum */
+int yolo_bn_pool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax, int N, int H, int W, int C,
+                     int Ho, int Wo, int pad_t, int pad_l, int relu, void* stream);
+/* g = dout * (out > 0 if relu); partial[rows][3][C] = (sum g, sum g*xhat(y), sum g*xhat(y2)) */
+int yolo_bn_act_bwd_reduce(const void* dout, const void* out, int relu, const void* y, const float* mean, const float* rstd,
+                           const void* y2, const float* mean2, const float* rstd2, int M, int C, float* partial, void* stream);
+/* dgamma = sum g*xhat, dbeta = sum g (NULL = skip), k1 = dbeta/count, k2 = dgamma/count; which = 1 (y) or 2 (y2) */
+int yolo_bn_bwd_finalize(const float* partial, int P, int C, int which, float count, float* dgamma, float* dbeta, float* k1, float* k2,
+                         void* stream);
+/* dy (=|+=) a1*(g - k1 - xhat*k2) (a1 NULL: dy = g); optional second BN branch -> dy2; optional dres (=|+=) g */
+int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu, const void* y, const float* a1, const float* mean,
+                          const float* rstd, const float* k1, const float* k2, void* dy, int acc_dy, const void* y2, const float* a2,
+                          const float* mean2, const float* rstd2, const float* k1b, const float* k2b, void* dy2, void* dres,
+                          int acc_dres, int64_t M, int C, void* stream);
+/* the same two passes through the stem's max-pool (rows = pre-pool pixels N*H*W) */
+int yolo_bn_pool_bwd_reduce(const void* dout, const void* out, const uint8_t* argmax, int relu, const void* y, const float* mean,
+                            const float* rstd, int N, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, float* partial,
+                            void* stream);
+int yolo_bn_pool_bwd_apply(const void* dout, const void* out, const uint8_t* argmax, int relu, const void* y, const float* a1,
+                           const float* mean, const float* rstd, const float* k1, const float* k2, void* dy, int N, int H, int W, int C,
+                           int Ho, int Wo, int pad_t, int pad_l, void* stream);
+/* gradient of concat(upsample2x(a), b): da[N,H/2,W/2,C0] (=|+=) 2x2 sums of dcat[..., :C0]; db[N,H,W,C1] (=|+=) dcat[..., C0:]
+ * (/root/reference/yolov3/yolov3_detector.py:115-116,140-141) */
+int yolo_upcat_split_bwd(const void* dcat, void* da, int acc_a, void* db, int acc_b, int N, int H, int W, int C0, int C1, void* stream);
+/* float32 NHWC images (C = 3, [0,1], BGR: /root/reference/dataset/file_util.py:58-59) -> bf16 NHWC8, channels 3..7 zero */
+int yolo_pack_input(const float* images, void* out, int64_t npix, int Cimg, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * YOLOv3 loss forward + backward.  Replaces YOLOv3Decoder.decode (/root/reference/yolov3/yolov3_decoder.py:62-192),
+ * LabelDecoder.decode (/root/reference/yolov3/label_decoder.py:26-60), YOLOv3Loss.loss
+ * (/root/reference/yolov3/yolov3_loss.py:81-369) and the TF gradient of the loss w.r.t. the head logits.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define YOLO_MAX_ANCHORS 8
+typedef struct {
+  int32_t H[3], W[3], B[3];          /* grid size and anchors per head, order /8, /16, /32 */
+  int32_t ldc[3];                    /* channel stride of the logits rows (>= B*L; conv outputs are padded) */
+  float anchor_w[3][YOLO_MAX_ANCHORS], anchor_h[3][YOLO_MAX_ANCHORS];   /* anchors in grid units (yolov3_decoder.py:38-40) */
+  int32_t L;                         /* box_len = 5 + class_num (configs.py:44) */
+  int32_t T;                         /* label slots per image; labels are float32 [N][T][5], padded with -1 */
+  float iou_thresh;                  /* configs.py:50 */
+  float w_xy[3], w_wh[3], w_noobj[3], w_obj[3], w_cls[3];   /* configs.py:52, transposed per head */
+  float w_rect[3];                   /* rectified_loss_weight (configs.py:59) */
+  int32_t rectified_coord_num;       /* configs.py:58; -1 disables */
+  int32_t is_focal_loss;
+  float focal_alpha, focal_gamma;
+  int32_t is_tiou_recall;
+  float eps;                         /* K.epsilon() = 1e-8 (run.py:26) */
+} yolo_loss_config;
+
+int64_t yolo_loss_workspace_bytes(const yolo_loss_config* c, int N);
+/* logits*: float32 [N][H][W][ldc].  dlogits* (float32, may be NULL) and dlogits*_bf16 (may be NULL) get d(total)/d(logits)
+ * in the same layout (padding channels are never written).  current_num: device int32 rectified-image counter (advances by
+ * batch_global while active).  terms: float32 [6][3] (rows xy, wh, noobj, obj, class, rectified); total: float32 [1].
+ * assign_out (int32 [N][T][3], may be NULL): flat index (row*W+col)*B+anchor of the responsible prediction or -1;
+ * resp_iou_out (float32 [N][T][3], may be NULL). */
+int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_global, const float* logits8, const float* logits16,
+                      const float* logits32, const float* labels, float* dlogits8, float* dlogits16, float* dlogits32,
+                      void* dlogits8_bf16, void* dlogits16_bf16, void* dlogits32_bf16, int* current_num, float* terms, float* total,
+                      int* assign_out, float* resp_iou_out, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * RAdam + L2 regularisation over the flat parameter buffer.  Replaces RAdam.get_updates
+ * (/root/reference/utils/radam.py:56-107) and the Keras L2 regularisers (/root/reference/backbone/basic_backbone.py:41,64,76).
+ * sched: device float32 [4] = {lr (host-set), lr_t, rho_t, adaptive}; iterations: device int64 [1].
+ * ------------------------------------------------------------------------------------------------------------------ */
+int yolo_radam_schedule(float* sched, int64_t* iterations, float beta1, float beta2, float decay, float warmup_coef, void* stream);
+int yolo_radam_l2_blocks(int64_t n);   /* length of l2_partial */
+/* n (multiple of 256) elements; l2_table[n/256] = lambda of each 256-element chunk; grads are multiplied by grad_scale and
+ * zeroed afterwards if zero_grad; params_bf16 (may be NULL) receives the bf16 copy; vhat (may be NULL) enables AMSGrad;
+ * l2_partial (may be NULL) receives per-workgroup sums of lambda*p^2 at the pre-update weights. */
+int yolo_radam_l2_step(float* params, float* grads, float* m, float* v, float* vhat, void* params_bf16, const float* l2_table,
+                       int64_t n, const float* sched, float beta1, float beta2, float eps, float grad_scale, int zero_grad,
+                       float* l2_partial, void* stream);
+int yolo_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+int yolo_sum_partials(const float* partial, int n, const float* add, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOV3_AMD_H_ */

@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/*.h declares, and the
+ctypes table covers exactly that set (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'yolov3_amd.h')
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(yolo_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_declares_functions():
+    names = declared_functions()
+    assert 'yolo_conv2d_fwd' in names and 'yolo_loss_fwd_bwd' in names and 'yolo_radam_l2_step' in names
+    assert len(names) >= 25
+
+
+def test_library_exports_every_declared_symbol():
+    from yolov3_tensorflow_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail('libyolov3_amd.so is not built (run __graft_entry__.build())')
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), 'missing export ' + name
+    assert lib.yolo_abi_version() == 1
+
+
+def test_ctypes_table_matches_header():
+    from yolov3_tensorflow_amd import _lib
+    assert sorted(_lib.SIGNATURES.keys()) == declared_functions()
+
+
+def test_argument_validation_without_gpu():
+    """argument checks run on the host before any launch, so they are testable here"""
+    from yolov3_tensorflow_amd import _lib
+    lib = _lib.load()
+    p = _lib.ConvProblem(1, 8, 8, 12, 0, 64, 3, 3, 1, 1, 1, 8, 8)      # Cin/8 not a power of two
+    assert lib.yolo_conv2d_fwd(ctypes.byref(p), None, None, None, None, None, 0, None, None, None) == -1
+    assert b'Cin' in lib.yolo_last_error()
+    p = _lib.ConvProblem(1, 8, 8, 64, 0, 100, 3, 3, 1, 1, 1, 8, 8)     # Cout not padded
+    assert lib.yolo_conv2d_fwd(ctypes.byref(p), None, None, None, None, None, 0, None, None, None) == -1
+    assert lib.yolo_radam_l2_step(None, None, None, None, None, None, None, 256, None, 0.9, 0.999, 1e-8, 1.0, 1, None, None) == -1
+    assert lib.yolo_reduce_rows(100, 24) == -1       # 256 % (C/8) != 0
+    assert lib.yolo_reduce_rows(100, 64) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from yolov3_tensorflow_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libyolov3_amd.so')
+    with pytest.raises(_lib.YoloNativeError):
+        _lib.load()

@@ -1,0 +1,432 @@
+"""GPU parity tests of the individual HIP kernels (through the C-ABI) against float32 CPU references on the SAME inputs.
+
+Floating-point tolerances (stated per test): bf16 operands are exactly representable in the float32 reference, so the only
+differences are accumulation order (float32) and the final bf16 rounding of outputs (<= 2^-8 relative).
+"""
+import math
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from yolov3_tensorflow_amd import _lib
+    _lib.load()          # fail loudly if the native library is missing
+    return torch.device('cuda:0')
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def ref_conv(x, w_hwio, stride, pt, pl, Ho, Wo):
+    """float32 conv of NHWC x with HWIO w and explicit top/left padding (bottom/right as needed)"""
+    N, H, W, Cc = x.shape
+    k = w_hwio.shape[0]
+    pb = max((Ho - 1) * stride + k - H - pt, 0)
+    pr = max((Wo - 1) * stride + k - W - pl, 0)
+    xin = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    return F.conv2d(xin, w_hwio.permute(3, 2, 0, 1), stride=stride)[:, :, :Ho, :Wo].permute(0, 2, 3, 1)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, padding
+    (2, 13, 13, 64, 64, 3, 1, 'same'),
+    (3, 12, 20, 64, 128, 3, 2, 'same'),     # TF same s2 on even sizes: pad (0,1)
+    (2, 11, 9, 128, 64, 3, 2, 'same'),      # odd sizes: pad (1,1)
+    (2, 10, 10, 256, 128, 1, 1, 'same'),
+    (2, 10, 14, 64, 128, 1, 2, 'valid'),    # NIN shortcut
+    (2, 16, 16, 8, 64, 3, 2, 'same'),       # stem (RGB padded to 8 channels), K = 72 not a multiple of 64
+    (1, 7, 7, 512, 256, 3, 1, 'same'),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    from yolov3_tensorflow_amd import ops
+    N, H, W, Cin, Cout, k, s, padding = case
+    g = torch.Generator().manual_seed(1234)
+    x = bf(torch.randn(N, H, W, Cin, generator=g))
+    if Cin == 8:
+        x[..., 3:] = 0
+    w = bf(torch.randn(k, k, Cin, Cout, generator=g) * (1.0 / math.sqrt(k * k * Cin)))
+    p = ops.conv_problem(N, H, W, Cin, Cout, k, s, padding)
+    Ho, Wo = p.Ho, p.Wo
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    y_ref = ref_conv(xr, wr, s, p.pad_t, p.pad_l, Ho, Wo)
+    dy = bf(torch.randn(N, Ho, Wo, Cout, generator=g))
+    y_ref.backward(dy.float())
+
+    xd = x.to(dev)
+    w_fwd = w.permute(3, 0, 1, 2).contiguous().to(dev)          # [Cout][R][S][Cin]
+    y = torch.empty(N, Ho, Wo, Cout, dtype=torch.bfloat16, device=dev)
+    rows = ops.conv2d_stat_rows(p)
+    ssum = torch.zeros(rows, Cout, device=dev)
+    ssq = torch.zeros(rows, Cout, device=dev)
+    ops.conv2d_fwd(p, xd, w_fwd, y, stat_sum=ssum, stat_sq=ssq)
+    torch.cuda.synchronize()
+    yc = y.float().cpu()
+    # tolerance: bf16 output rounding (2^-8 relative) + float32 accumulation-order noise
+    torch.testing.assert_close(yc, y_ref.detach(), rtol=1e-2, atol=1e-2)
+    # BN partial statistics are sums of the stored (rounded) outputs
+    torch.testing.assert_close(ssum.sum(0).cpu(), yc.sum(dim=(0, 1, 2)), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(ssq.sum(0).cpu(), (yc * yc).sum(dim=(0, 1, 2)), rtol=1e-3, atol=1e-2)
+
+    # float32 output + bias
+    bias = torch.randn(Cout, generator=g)
+    y32 = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32, device=dev)
+    ops.conv2d_fwd(p, xd, w_fwd, y32, bias=bias.to(dev))
+    torch.testing.assert_close(y32.cpu(), y_ref.detach() + bias, rtol=1e-4, atol=1e-4)
+
+    # wgrad (float32 atomics into a zeroed buffer, [Cout][R][S][Cin])
+    dyd = dy.to(dev)
+    dw = torch.zeros(Cout, k, k, Cin, device=dev)
+    ops.conv2d_wgrad(p, xd, dyd, dw)
+    dw_ref = wr.grad.permute(3, 0, 1, 2)
+    scale = dw_ref.abs().max().item()
+    torch.testing.assert_close(dw.cpu(), dw_ref, rtol=1e-3, atol=1e-4 * max(scale, 1.0))
+    # explicit split-K must agree
+    dw2 = torch.zeros_like(dw)
+    ops.conv2d_wgrad(p, xd, dyd, dw2, split_k=3)
+    torch.testing.assert_close(dw2.cpu(), dw_ref, rtol=1e-3, atol=1e-4 * max(scale, 1.0))
+
+    if Cin % 64 == 0:
+        w_dg = torch.empty(Cin, k, k, Cout, dtype=torch.bfloat16, device=dev)
+        ops.repack_dgrad_weights(w_fwd, w_dg, Cout, k, k, Cin)
+        ref_dg = w.permute(2, 0, 1, 3).flip(1, 2).contiguous()
+        assert torch.equal(w_dg.cpu(), ref_dg)
+        dx = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
+        ops.conv2d_dgrad(p, dyd, w_dg, dx)
+        torch.testing.assert_close(dx.float().cpu(), xr.grad, rtol=1e-2, atol=1e-2)
+        ops.conv2d_dgrad(p, dyd, w_dg, dx, accumulate=True)        # fan-in accumulation: dx += dgrad
+        torch.testing.assert_close(dx.float().cpu(), 2 * xr.grad, rtol=2e-2, atol=2e-2)
+
+
+def test_conv_fused_upsample_concat(dev):
+    """1x1 conv over concat(upsample2x(a), b) without materialising the concat (yolov3_detector.py:115-118)"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(7)
+    N, H, W, C0, C1, Cout = 2, 12, 8, 64, 64, 128
+    a = bf(torch.randn(N, H // 2, W // 2, C0, generator=g))
+    b = bf(torch.randn(N, H, W, C1, generator=g))
+    w = bf(torch.randn(1, 1, C0 + C1, Cout, generator=g) * 0.1)
+    cat = torch.cat([a.float().repeat_interleave(2, 1).repeat_interleave(2, 2), b.float()], dim=-1).requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    y_ref = ref_conv(cat, wr, 1, 0, 0, H, W)
+    dy = bf(torch.randn(N, H, W, Cout, generator=g))
+    y_ref.backward(dy.float())
+    p = ops.conv_problem(N, H, W, C0 + C1, Cout, 1, 1, 'same', C0=C0)
+    w_fwd = w.permute(3, 0, 1, 2).contiguous().to(dev)
+    y = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    ops.conv2d_fwd(p, b.to(dev), w_fwd, y, src0=a.to(dev))
+    torch.testing.assert_close(y.float().cpu(), y_ref.detach(), rtol=1e-2, atol=1e-2)
+    dw = torch.zeros(Cout, 1, 1, C0 + C1, device=dev)
+    ops.conv2d_wgrad(p, b.to(dev), dy.to(dev), dw, src0=a.to(dev))
+    torch.testing.assert_close(dw.cpu(), wr.grad.permute(3, 0, 1, 2), rtol=1e-3, atol=1e-3)
+    # dgrad over the virtual concat, then the split kernel
+    pd = ops.conv_problem(N, H, W, C0 + C1, Cout, 1, 1, 'same')
+    w_dg = torch.empty(C0 + C1, 1, 1, Cout, dtype=torch.bfloat16, device=dev)
+    ops.repack_dgrad_weights(w_fwd, w_dg, Cout, 1, 1, C0 + C1)
+    dcat = torch.empty(N, H, W, C0 + C1, dtype=torch.bfloat16, device=dev)
+    ops.conv2d_dgrad(pd, dy.to(dev), w_dg, dcat)
+    da = torch.empty(N, H // 2, W // 2, C0, dtype=torch.bfloat16, device=dev)
+    db = torch.full((N, H, W, C1), 1.0, dtype=torch.bfloat16, device=dev)
+    ops.upcat_split_bwd(dcat, da, False, db, True, N, H, W, C0, C1)
+    gcat = cat.grad
+    da_ref = gcat[..., :C0].reshape(N, H // 2, 2, W // 2, 2, C0).sum(dim=(2, 4))
+    torch.testing.assert_close(da.float().cpu(), da_ref, rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(db.float().cpu(), gcat[..., C0:] + 1.0, rtol=2e-2, atol=3e-2)
+
+
+def _bn_ref(y, gamma, beta, eps=1e-5):
+    m = y.mean(dim=(0, 1, 2))
+    v = ((y - m) ** 2).mean(dim=(0, 1, 2))
+    return (y - m) * torch.rsqrt(v + eps) * gamma + beta, m, v
+
+
+@pytest.mark.parametrize('mode', ['plain', 'res', 'res_bn'])
+def test_bn_act_fwd_bwd(dev, mode):
+    """conv-output statistics -> finalize -> apply(+residual)(+ReLU), and the two backward passes, vs autograd"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(11)
+    N, H, W, Cc = 3, 9, 7, 64
+    M = N * H * W
+    y = bf(torch.randn(N, H, W, Cc, generator=g) * 2 + 0.5)
+    y2 = bf(torch.randn(N, H, W, Cc, generator=g))
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    gamma2, beta2 = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    dout = bf(torch.randn(N, H, W, Cc, generator=g))
+
+    yr, y2r = y.float().requires_grad_(True), y2.float().requires_grad_(True)
+    gr, br, g2r, b2r = [t.clone().requires_grad_(True) for t in (gamma, beta, gamma2, beta2)]
+    o, m1, v1 = _bn_ref(yr, gr, br)
+    if mode == 'res':
+        o = o + y2r
+    elif mode == 'res_bn':
+        o2, m2, v2 = _bn_ref(y2r, g2r, b2r)
+        o = o + o2
+    out_ref = torch.relu(o)
+    out_ref_b = bf(out_ref.detach())
+    out_ref.backward(dout.float())      # relu mask of the float32 output == mask of the stored bf16 output (rounding keeps sign)
+
+    d = lambda t: t.to(dev)
+    yd, y2d = d(y), d(y2)
+
+    def stats(x):
+        rows = ops.reduce_rows(M, Cc)
+        part = torch.empty(rows, 2, Cc, device=dev)
+        ops.bn_stats(x, M, Cc, part)
+        return part, rows
+
+    def finalize(part, rows, ga, be):
+        sc, sh, mean, rstd = [torch.empty(Cc, device=dev) for _ in range(4)]
+        mm, mv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+        ops.bn_finalize(part, part[0, 1], rows, 2 * Cc, Cc, M, d(ga), d(be), 1e-5, 0.9, mm, mv, sc, sh, mean, rstd)
+        return sc, sh, mean, rstd, mm, mv
+
+    part, rows = stats(yd)
+    sc, sh, mean, rstd, mm, mv = finalize(part, rows, gamma, beta)
+    torch.testing.assert_close(mean.cpu(), m1.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rstd.cpu(), torch.rsqrt(v1.detach() + 1e-5), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(mm.cpu(), 0.1 * m1.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(mv.cpu(), 0.9 + 0.1 * v1.detach() * M / (M - 1), rtol=1e-4, atol=1e-5)
+    out = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=dev)
+    kw = {}
+    if mode == 'res':
+        kw = dict(res=y2d)
+    elif mode == 'res_bn':
+        part2, rows2 = stats(y2d)
+        sc2, sh2, mean2, rstd2, _, _ = finalize(part2, rows2, gamma2, beta2)
+        kw = dict(res=y2d, res_scale=sc2, res_shift=sh2)
+    ops.bn_act_fwd(yd, sc, sh, out, M, Cc, True, **kw)
+    torch.testing.assert_close(out.float().cpu(), out_ref_b.float(), rtol=1e-2, atol=1e-2)
+
+    # ---- backward ----
+    out_d, dout_d = d(out_ref_b), d(dout)       # use the reference's stored output so masks agree exactly
+    P = ops.reduce_rows(M, Cc)
+    partial = torch.empty(P, 3, Cc, device=dev)
+    if mode == 'res_bn':
+        ops.bn_act_bwd_reduce(dout_d, out_d, True, yd, mean, rstd, M, Cc, partial, y2=y2d, mean2=mean2, rstd2=rstd2)
+    else:
+        ops.bn_act_bwd_reduce(dout_d, out_d, True, yd, mean, rstd, M, Cc, partial)
+    dga, dbe, k1, k2 = [torch.empty(Cc, device=dev) for _ in range(4)]
+    ops.bn_bwd_finalize(partial, P, Cc, 1, M, dga, dbe, k1, k2)
+    torch.testing.assert_close(dga.cpu(), gr.grad, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(dbe.cpu(), br.grad, rtol=2e-3, atol=2e-3)
+    dy = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=dev)
+    if mode == 'plain':
+        ops.bn_act_bwd_apply(dout_d, out_d, True, M, Cc, y=yd, a1=sc, mean=mean, rstd=rstd, k1=k1, k2=k2, dy=dy)
+    elif mode == 'res':
+        dres = torch.empty_like(dy)
+        ops.bn_act_bwd_apply(dout_d, out_d, True, M, Cc, y=yd, a1=sc, mean=mean, rstd=rstd, k1=k1, k2=k2, dy=dy, dres=dres)
+        torch.testing.assert_close(dres.float().cpu(), y2r.grad, rtol=1e-2, atol=1e-2)
+    else:
+        dga2, dbe2, k1b, k2b = [torch.empty(Cc, device=dev) for _ in range(4)]
+        ops.bn_bwd_finalize(partial, P, Cc, 2, M, dga2, dbe2, k1b, k2b)
+        torch.testing.assert_close(dga2.cpu(), g2r.grad, rtol=2e-3, atol=2e-3)
+        torch.testing.assert_close(dbe2.cpu(), b2r.grad, rtol=2e-3, atol=2e-3)
+        dy2 = torch.empty_like(dy)
+        ops.bn_act_bwd_apply(dout_d, out_d, True, M, Cc, y=yd, a1=sc, mean=mean, rstd=rstd, k1=k1, k2=k2, dy=dy,
+                             y2=y2d, a2=sc2, mean2=mean2, rstd2=rstd2, k1b=k1b, k2b=k2b, dy2=dy2)
+        torch.testing.assert_close(dy2.float().cpu(), y2r.grad, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-2)
+
+
+def test_bn_pool_relu_fwd_bwd(dev):
+    """stem: conv -> BN -> maxpool(3,2,'same') -> ReLU (resnet18.py:59-61) and its backward"""
+    from yolov3_tensorflow_amd import ops
+    from oracle.nets import same_pad
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Cc = 2, 12, 10, 64
+    M = N * H * W
+    # distinct values per channel so the arg-max is unique (ties are resolved first-max by both sides anyway)
+    y = bf(torch.randn(N, H, W, Cc, generator=g))
+    gamma, beta = torch.rand(Cc, generator=g) - 0.3, torch.randn(Cc, generator=g) * 0.1      # some negative gammas
+    yr, gr, br = y.float().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    o, m1, v1 = _bn_ref(yr, gr, br)
+    (pt, pb), (pl, pr) = same_pad(H, 3, 2), same_pad(W, 3, 2)
+    pooled = F.max_pool2d(F.pad(o.permute(0, 3, 1, 2), (pl, pr, pt, pb), value=float('-inf')), 3, 2).permute(0, 2, 3, 1)
+    out_ref = torch.relu(pooled)
+    Ho, Wo = out_ref.shape[1], out_ref.shape[2]
+    dout = bf(torch.randn(N, Ho, Wo, Cc, generator=g))
+    out_b = bf(out_ref.detach())
+    out_ref.backward(dout.float())
+    d = lambda t: t.to(dev)
+    yd = d(y)
+    rows = ops.reduce_rows(M, Cc)
+    part = torch.empty(rows, 2, Cc, device=dev)
+    ops.bn_stats(yd, M, Cc, part)
+    sc, sh, mean, rstd = [torch.empty(Cc, device=dev) for _ in range(4)]
+    ops.bn_finalize(part, part[0, 1], rows, 2 * Cc, Cc, M, d(gamma), d(beta), 1e-5, 0.9, None, None, sc, sh, mean, rstd)
+    out = torch.empty(N, Ho, Wo, Cc, dtype=torch.bfloat16, device=dev)
+    arg = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=dev)
+    ops.bn_pool_fwd(yd, sc, sh, out, arg, N, H, W, Cc, Ho, Wo, pt, pl, True)
+    torch.testing.assert_close(out.float().cpu(), out_b.float(), rtol=1e-2, atol=1e-2)
+    partial = torch.empty(rows, 3, Cc, device=dev)
+    ops.bn_pool_bwd_reduce(d(dout), out, arg, True, yd, mean, rstd, N, H, W, Cc, Ho, Wo, pt, pl, partial)
+    dga, dbe, k1, k2 = [torch.empty(Cc, device=dev) for _ in range(4)]
+    ops.bn_bwd_finalize(partial, rows, Cc, 1, M, dga, dbe, k1, k2)
+    torch.testing.assert_close(dga.cpu(), gr.grad, rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(dbe.cpu(), br.grad, rtol=5e-3, atol=5e-3)
+    dy = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=dev)
+    ops.bn_pool_bwd_apply(d(dout), out, arg, True, yd, sc, mean, rstd, k1, k2, dy, N, H, W, Cc, Ho, Wo, pt, pl)
+    torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-2)
+
+
+def test_pack_input(dev):
+    from yolov3_tensorflow_amd import ops
+    img = torch.rand(2, 6, 5, 3)
+    out = torch.empty(2, 6, 5, 8, dtype=torch.bfloat16, device=dev)
+    ops.pack_input(img.to(dev), out, 2 * 6 * 5, 3)
+    ref = torch.zeros(2, 6, 5, 8)
+    ref[..., :3] = img
+    assert torch.equal(out.cpu(), bf(ref))
+
+
+# ------------------------------------------------------------------------------------------------------------------ loss
+ANCHORS = [[(0.06618181818181816, 0.1025177510694752), (0.18544278606965178, 0.13160367921287464), (0.13, 0.32733333333333337)],
+           [(0.13, 0.32733333333333337), (0.303806787732042, 0.34370030784316496)],
+           [(0.303806787732042, 0.34370030784316496), (0.4667050847457627, 0.5281262429095761),
+            (0.7906945888923907, 0.7888860433597275)]]      # /root/reference/configs.py:37-41
+LOSS_W = [(5, 5, 0.05, 3, 1), (8, 8, 0.05, 2, 1), (10, 10, 0.05, 2, 1)]     # configs.py:52
+
+
+def make_labels(gen, N, T, class_num, empty_image=None):
+    lab = -torch.ones(N, T, 5)
+    for n in range(N):
+        if n == empty_image:
+            continue
+        k = int(torch.randint(1, T + 1, (1,), generator=gen))
+        wh = torch.rand(k, 2, generator=gen) * 0.5 + 0.04
+        xy = torch.rand(k, 2, generator=gen) * (1 - wh) + wh / 2
+        cls = torch.randint(0, max(class_num, 1), (k, 1), generator=gen).float()
+        lab[n, :k] = torch.cat([xy, wh, cls], dim=1)
+    return lab
+
+
+LOSS_CASES = [
+    dict(name='c13_rect', grid=[(40, 40), (20, 20), (10, 10)], C=13, N=3, T=8, rect=1464, focal=False, tiou=False, empty=None),
+    dict(name='c80_norect_empty', grid=[(16, 16), (8, 8), (4, 4)], C=80, N=4, T=6, rect=-1, focal=False, tiou=False, empty=2),
+    dict(name='c0_rect', grid=[(12, 16), (6, 8), (3, 4)], C=0, N=2, T=5, rect=0, focal=False, tiou=False, empty=None),
+    dict(name='c20_focal_tiou', grid=[(16, 16), (8, 8), (4, 4)], C=20, N=3, T=7, rect=-1, focal=True, tiou=True, empty=None),
+]
+
+
+@pytest.mark.parametrize('case', LOSS_CASES, ids=[c['name'] for c in LOSS_CASES])
+def test_loss_fwd_bwd_vs_oracle(dev, case):
+    """tolerance: loss terms 1e-4 relative (float32, different summation order); d(logits) 1e-3 relative (north_star);
+    responsible-anchor indices exact."""
+    from yolov3_tensorflow_amd import ops
+    from oracle.loss import YOLOv3LossOracle
+    gen = torch.Generator().manual_seed(42)
+    grid, Cn, N, T = case['grid'], case['C'], case['N'], case['T']
+    L = 5 + Cn
+    B = [len(a) for a in ANCHORS]
+    ldc = [ops.pad_channels(b * L) for b in B]
+    raw = [torch.randn(N, h, w, b, L, generator=gen) * 0.8 for (h, w), b in zip(grid, B)]
+    lab = make_labels(gen, N, T, Cn, case['empty'])
+    orc = YOLOv3LossOracle(grid, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=case['rect'], rectified_loss_weight=[1.0, 0.5, 2.0],
+                           is_focal_loss=case['focal'], focal_alpha=1.0, focal_gamma=2.0, is_tiou_recall=case['tiou'])
+    rr = [r.clone().requires_grad_(True) for r in raw]
+    total_ref = orc.loss_heads(lab.reshape(N, -1), rr)
+    total_ref.backward()
+    terms_ref = torch.zeros(6, 3)
+    terms_ref[:orc.terms.shape[0]] = orc.terms
+
+    cfg = ops.make_loss_config(grid, Cn, ANCHORS, 0.5, LOSS_W, ldc, T, rectified_coord_num=case['rect'],
+                               rectified_loss_weight=[1.0, 0.5, 2.0], is_focal_loss=case['focal'], focal_alpha=1.0, focal_gamma=2.0,
+                               is_tiou_recall=case['tiou'])
+    logits, dl, dlb = [], [], []
+    for h in range(3):
+        gh, gw = grid[h]
+        t = torch.zeros(N, gh, gw, ldc[h])
+        t[..., :B[h] * L] = raw[h].reshape(N, gh, gw, B[h] * L)
+        logits.append(t.to(dev))
+        dl.append(torch.zeros(N, gh, gw, ldc[h], device=dev))
+        dlb.append(torch.zeros(N, gh, gw, ldc[h], dtype=torch.bfloat16, device=dev))
+    ws = torch.empty(ops.loss_workspace_bytes(cfg, N), dtype=torch.uint8, device=dev)
+    cur = torch.zeros(1, dtype=torch.int32, device=dev)
+    terms = torch.empty(6, 3, device=dev)
+    total = torch.empty(1, device=dev)
+    assign = torch.empty(N, T, 3, dtype=torch.int32, device=dev)
+    riou = torch.empty(N, T, 3, device=dev)
+    ops.loss_fwd_bwd(cfg, N, N, logits, lab.to(dev), cur, terms, total, ws, dlogits=dl, dlogits_bf16=dlb, assign_out=assign,
+                     resp_iou_out=riou)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(terms.cpu(), terms_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(total.cpu()[0], total_ref.detach(), rtol=1e-4, atol=1e-5)
+    # rectified counter semantics (yolov3_loss.py:125-130,152)
+    expect_cur = N if (case['rect'] >= 0) else 0
+    assert int(cur.cpu()[0]) == expect_cur
+    # responsible-anchor indices: exact
+    a = assign.cpu().numpy()
+    for n in range(N):
+        valid_t = [t for t in range(T) if lab[n, t, 0] >= 0]
+        for h in range(3):
+            got = sorted(int(a[n, t, h]) for t in valid_t if a[n, t, h] >= 0)
+            ref = orc.last_assign[n][h]
+            W_, B_ = grid[h][1], B[h]
+            exp = sorted(int((r * W_ + c) * B_ + k) for r, c, k in ref.tolist())
+            assert got == exp, (n, h, got, exp)
+        for t in range(T):
+            if lab[n, t, 0] < 0:
+                assert (a[n, t] == -1).all()
+    # gradients
+    for h in range(3):
+        gh, gw = grid[h]
+        gref = rr[h].grad.reshape(N, gh, gw, B[h] * L)
+        got = dl[h].cpu()
+        assert torch.count_nonzero(got[..., B[h] * L:]) == 0
+        denom = gref.abs().max().item()
+        torch.testing.assert_close(got[..., :B[h] * L], gref, rtol=1e-3, atol=1e-5 * max(denom, 1.0))
+        torch.testing.assert_close(dlb[h].float().cpu(), got.to(torch.bfloat16).float(), rtol=0, atol=0)
+    # second call: counter advanced -> rectified term switches off when current_num > rectified_coord_num
+    ops.loss_fwd_bwd(cfg, N, N, logits, lab.to(dev), cur, terms, total, ws, dlogits=dl)
+    total2 = orc.loss_heads(lab.reshape(N, -1), [r.clone() for r in raw])
+    torch.testing.assert_close(total.cpu()[0], total2.detach(), rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------ RAdam
+def test_radam_l2_step_vs_oracle(dev):
+    """10 steps across the rho_t = 5 switch (t = 6 for beta_2 = .999) with L2 on one segment; tolerance 1e-6 absolute /
+    1e-5 relative (float32 elementwise; powf vs numpy power differ by ulps)."""
+    from yolov3_tensorflow_amd import ops
+    from oracle.optim import RAdamOracle
+    rng = np.random.default_rng(0)
+    n = 1024
+    p0 = rng.normal(size=n).astype(np.float32)
+    lam = np.zeros(n // 256, dtype=np.float32)
+    lam[1], lam[2] = 5e-4, 1e-5
+    lam_e = np.repeat(lam, 256)
+    orc = RAdamOracle(lr=1e-3)
+    pr = p0.copy()
+    d = lambda a: torch.from_numpy(a).to(dev)
+    p, m, v = d(p0.copy()), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    sched = torch.tensor([1e-3, 0, 0, 0], device=dev)
+    it = torch.zeros(1, dtype=torch.int64, device=dev)
+    l2p = torch.empty(ops.radam_l2_blocks(n), device=dev)
+    l2out = torch.empty(1, device=dev)
+    for step in range(10):
+        g = rng.normal(size=n).astype(np.float32)
+        l2_ref = float((lam_e * pr * pr).sum())
+        rho, lr_t = orc.step([pr], [g + 2 * lam_e * pr])
+        gd = d(g.copy())
+        ops.radam_schedule(sched, it, 0.9, 0.999, 0.0, 1.0)
+        ops.radam_l2_step(p, gd, m, v, d(lam), n, sched, 0.9, 0.999, 1e-8, 1.0, True, params_bf16=pb, l2_partial=l2p)
+        ops.sum_partials(l2p, l2p.numel(), None, l2out)
+        s = sched.cpu().numpy()
+        assert int(it.cpu()[0]) == step + 1
+        assert (s[3] == 1.0) == (rho >= 5.0) and (step + 1 >= 6) == (s[3] == 1.0)
+        np.testing.assert_allclose(s[1], lr_t, rtol=1e-5)
+        np.testing.assert_allclose(p.cpu().numpy(), pr, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(l2out.cpu().numpy()[0], l2_ref, rtol=1e-5)
+        assert torch.count_nonzero(gd) == 0
+        assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))

@@ -1,0 +1,92 @@
+"""ctypes binding of the C-ABI in include/yolov3_amd.h (libyolov3_amd.so, built by csrc/Makefile).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libyolov3_amd.so')
+
+MAX_ANCHORS = 8
+
+
+class ConvProblem(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ('N', 'H', 'W', 'Cin', 'C0', 'Cout', 'R', 'S', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo')]
+
+
+class LossConfig(C.Structure):
+    _fields_ = [('H', C.c_int32 * 3), ('W', C.c_int32 * 3), ('B', C.c_int32 * 3), ('ldc', C.c_int32 * 3),
+                ('anchor_w', (C.c_float * MAX_ANCHORS) * 3), ('anchor_h', (C.c_float * MAX_ANCHORS) * 3),
+                ('L', C.c_int32), ('T', C.c_int32), ('iou_thresh', C.c_float),
+                ('w_xy', C.c_float * 3), ('w_wh', C.c_float * 3), ('w_noobj', C.c_float * 3), ('w_obj', C.c_float * 3),
+                ('w_cls', C.c_float * 3), ('w_rect', C.c_float * 3),
+                ('rectified_coord_num', C.c_int32), ('is_focal_loss', C.c_int32),
+                ('focal_alpha', C.c_float), ('focal_gamma', C.c_float), ('is_tiou_recall', C.c_int32), ('eps', C.c_float)]
+
+
+P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+CP = C.POINTER(ConvProblem)
+LP = C.POINTER(LossConfig)
+
+# name -> (restype, argtypes); must list every function declared in include/yolov3_amd.h
+SIGNATURES = {
+    'yolo_abi_version': (I, []),
+    'yolo_last_error': (C.c_char_p, []),
+    'yolo_conv2d_stat_rows': (I, [CP]),
+    'yolo_conv2d_fwd': (I, [CP, P, P, P, P, P, I, P, P, P]),
+    'yolo_conv2d_dgrad': (I, [CP, P, P, P, I, P]),
+    'yolo_conv2d_wgrad': (I, [CP, P, P, P, P, I, P]),
+    'yolo_repack_dgrad_weights': (I, [P, P, I, I, I, I, P]),
+    'yolo_reduce_rows': (I, [I, I]),
+    'yolo_bn_stats': (I, [P, I, I, P, P]),
+    'yolo_bn_finalize': (I, [P, P, I, I64, I, F, P, P, F, F, P, P, P, P, P, P, P]),
+    'yolo_bn_act_fwd': (I, [P, P, P, P, P, P, P, I64, I, I, P]),
+    'yolo_bn_pool_fwd': (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    'yolo_bn_act_bwd_reduce': (I, [P, P, I, P, P, P, P, P, P, I, I, P, P]),
+    'yolo_bn_bwd_finalize': (I, [P, I, I, I, F, P, P, P, P, P]),
+    'yolo_bn_act_bwd_apply': (I, [P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I64, I, P]),
+    'yolo_bn_pool_bwd_reduce': (I, [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    'yolo_bn_pool_bwd_apply': (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    'yolo_upcat_split_bwd': (I, [P, P, I, P, I, I, I, I, I, I, P]),
+    'yolo_pack_input': (I, [P, P, I64, I, P]),
+    'yolo_loss_workspace_bytes': (I64, [LP, I]),
+    'yolo_loss_fwd_bwd': (I, [LP, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'yolo_radam_schedule': (I, [P, P, F, F, F, F, P]),
+    'yolo_radam_l2_blocks': (I, [I64]),
+    'yolo_radam_l2_step': (I, [P, P, P, P, P, P, P, I64, P, F, F, F, F, I, P, P]),
+    'yolo_cast_f32_to_bf16': (I, [P, P, I64, P]),
+    'yolo_sum_partials': (I, [P, I, P, P, P]),
+}
+
+_lib = None
+
+
+class YoloNativeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libyolov3_amd.so (once).  Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YoloNativeError('%s not found: build it with `make -C %s` (or __graft_entry__.build()); the MI355X path has no '
+                              'fallback' % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.yolo_abi_version() != 1:
+        raise YoloNativeError('ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(status, what=''):
+    if status != 0:
+        msg = load().yolo_last_error()
+        raise YoloNativeError('%s failed with status %d: %s' % (what, status, msg.decode() if msg else ''))

@@ -1,0 +1,62 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the YOLOv3 training hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/yolov3_amd.h"
+
+typedef uint16_t bf16_t;  // storage type of a bfloat16 element
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define YOLO_WAVE 64
+
+// ---- error plumbing (C-ABI returns int status; message retrievable with yolo_last_error) ----
+void yolo_set_error(const char* fmt, ...);
+#define YOLO_CHECK_ARG(cond, msg)                                   \
+  do {                                                              \
+    if (!(cond)) {                                                  \
+      yolo_set_error("%s:%d: %s", __FILE__, __LINE__, msg);        \
+      return YOLO_ERR_INVALID_ARG;                                  \
+    }                                                               \
+  } while (0)
+#define YOLO_LAUNCH_CHECK()                                                              \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess) {                                                              \
+      yolo_set_error("%s:%d: launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return (int)e_;                                                                    \
+    }                                                                                    \
+  } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even; hipcc lowers the cast to v_cvt_pk_bf16_f32 on gfx950) ----
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ void unpack_bf8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack_bf8(const float* f) {
+  uint4 v;
+  v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]); v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+  return v;
+}
+
+// ---- wave / block reductions (64-wide wavefronts) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

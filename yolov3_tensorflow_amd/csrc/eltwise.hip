@@ -1,0 +1,545 @@
+// Bandwidth-bound kernels of the YOLOv3 training path on gfx950: BatchNorm (training mode) statistics / finalize / apply
+// fused with ReLU and the residual add, the stem's BN -> max-pool -> ReLU, their backward passes, the gradient split of
+// the fused upsample+concat, and the input packer.  All activations are NHWC bf16 moved as 16-byte vectors (8 channels
+// per lane); every per-channel quantity is float32.
+//
+// Reference call sites replaced: keras BatchNormalization (backbone/basic_backbone.py:75-77), Activation relu (:89),
+// layers.add (:124), MaxPooling2D (backbone/resnet18.py:60), UpSampling2D+concatenate gradients
+// (yolov3/yolov3_detector.py:115-116,140-141) and the TF autodiff of all of them.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+// ------------------------------------------------------------------------------------------------------------------
+// column-parallel partial reduction helper: thread (cv, rl) owns channel chunk cv (8 channels) and rows rl, rl+RL*grid...
+// ------------------------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[K][8], int C, float* __restrict__ partial /*[grid][K][C]*/) {
+  __shared__ float red[EW_THREADS * 8];  // [RL][C] floats per quantity (RL * C == 2048)
+  const int CV = C >> 3, RL = EW_THREADS / CV;
+  const int cv = threadIdx.x % CV, rl = threadIdx.x / CV;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl * C + cv * 8 + j] = acc[k][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+      float s = 0.f;
+      for (int r = 0; r < RL; ++r) s += red[r * C + c];
+      partial[((size_t)blockIdx.x * K + k) * C + c] = s;
+    }
+  }
+}
+
+__device__ __forceinline__ uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st16(bf16_t* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// ---- plain per-channel sum / sum of squares of a bf16 [M][C] tensor -> partial[grid][2][C] ----
+__global__ __launch_bounds__(EW_THREADS) void bn_stats_kernel(const bf16_t* __restrict__ x, int M, int C, float* __restrict__ partial) {
+  const int CV = C >> 3, RL = EW_THREADS / CV;
+  const int cv = threadIdx.x % CV, rl = threadIdx.x / CV;
+  float acc[2][8] = {};
+  for (int r = blockIdx.x * RL + rl; r < M; r += gridDim.x * RL) {
+    float v[8];
+    unpack_bf8(ld16(x + (size_t)r * C + cv * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[0][j] += v[j]; acc[1][j] += v[j] * v[j]; }
+  }
+  block_reduce_store<2>(acc, C, partial);
+}
+
+// forward finalize: batch mean / biased variance -> scale, shift, mean, rstd; moving statistics (momentum, unbiased var)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int P,
+                                                           size_t rstride, int C, float count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+  if (c >= C) return;  // C is a multiple of 32: whole block exits together
+  __shared__ double red[2][32][33];
+  double s = 0.0, q = 0.0;
+  for (int p = ry; p < P; p += 32) { s += (double)psum[(size_t)p * rstride + c]; q += (double)psq[(size_t)p * rstride + c]; }
+  red[0][ry][threadIdx.x & 31] = s;
+  red[1][ry][threadIdx.x & 31] = q;
+  __syncthreads();
+  if (ry == 0) {
+    s = 0.0; q = 0.0;
+    for (int r = 0; r < 32; ++r) { s += red[0][r][threadIdx.x & 31]; q += red[1][r][threadIdx.x & 31]; }
+    const double mean = s / (double)count;
+    double var = q / (double)count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * rstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    if (moving_mean) {
+      const double unb = count > 1.f ? var * ((double)count / ((double)count - 1.0)) : var;
+      moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
+      moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unb;
+    }
+  }
+}
+
+// ---- out = act(y * scale + shift + T),  T in {0, res, y2 * scale2 + shift2};  scale == nullptr means identity ----
+__global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const bf16_t* __restrict__ res,
+                                                                const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                                bf16_t* __restrict__ out, size_t nchunks, int C, int relu) {
+  const int CV = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_THREADS) {
+    const int c = (int)(i % CV) * 8;
+    float v[8];
+    unpack_bf8(ld16(y + i * 8), v);
+    if (scale) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * scale[c + j] + shift[c + j];
+    }
+    if (res) {
+      float r[8];
+      unpack_bf8(ld16(res + i * 8), r);
+      if (scale2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = r[j] * scale2[c + j] + shift2[c + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st16(out + i * 8, pack_bf8(v));
+  }
+}
+
+// ---- stem: out = act(maxpool3x3s2(y * scale + shift)), argmax (0..8, first maximum in row-major window order) ----
+__global__ __launch_bounds__(EW_THREADS) void bn_pool_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, bf16_t* __restrict__ out,
+                                                                 uint8_t* __restrict__ argmax, int N, int H, int W, int C, int Ho,
+                                                                 int Wo, int pt, int pl, int relu) {
+  const int CV = C >> 3;
+  const size_t total = (size_t)N * Ho * Wo * CV;
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_THREADS) {
+    const int cv = (int)(i % CV);
+    size_t pix = i / CV;
+    const int wo = (int)(pix % Wo); pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const int c = cv * 8;
+    float sc[8], sh[8], best[8];
+    int arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale ? scale[c + j] : 1.f; sh[j] = shift ? shift[c + j] : 0.f; best[j] = -INFINITY; arg[j] = 0; }
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = ho * 2 - pt + dh;
+      if (h < 0 || h >= H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = wo * 2 - pl + dw;
+        if (w < 0 || w >= W) continue;
+        float v[8];
+        unpack_bf8(ld16(y + ((size_t)(n * H + h) * W + w) * C + c), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = v[j] * sc[j] + sh[j];
+          if (t > best[j]) { best[j] = t; arg[j] = dh * 3 + dw; }
+        }
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], 0.f);
+    }
+    st16(out + i * 8, pack_bf8(best));
+    uint2 a;
+    a.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+    a.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+    *reinterpret_cast<uint2*>(argmax + i * 8) = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward.  g = dout * act'(out)   (plain), or the max-pool un-pooling gather of that (pooled stem).
+// ------------------------------------------------------------------------------------------------------------------
+struct PlainGrad {
+  const bf16_t* dout; const bf16_t* out; int relu; int C;
+  __device__ __forceinline__ void load(size_t row, int cv, float (&g)[8]) const {
+    unpack_bf8(ld16(dout + row * C + cv * 8), g);
+    if (relu) {
+      float o[8];
+      unpack_bf8(ld16(out + row * C + cv * 8), o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+    }
+  }
+};
+
+struct PoolGrad {  // rows index the PRE-pool map [N][H][W]
+  const bf16_t* dout; const bf16_t* out; const uint8_t* argmax; int relu; int C; int H, W, Ho, Wo, pt, pl;
+  __device__ __forceinline__ void load(size_t row, int cv, float (&g)[8]) const {
+    const int w = (int)(row % W);
+    size_t t = row / W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hn = h + pt - dh;
+      if (hn < 0 || (hn & 1)) continue;
+      const int ho = hn >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wn = w + pl - dw;
+        if (wn < 0 || (wn & 1)) continue;
+        const int wo = wn >> 1;
+        if (wo >= Wo) continue;
+        const size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * 8;
+        const uint2 a = *reinterpret_cast<const uint2*>(argmax + o);
+        float d[8], ov[8];
+        unpack_bf8(ld16(dout + o), d);
+        if (relu) unpack_bf8(ld16(out + o), ov);
+        const int code = dh * 3 + dw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int aj = (j < 4 ? (a.x >> (8 * j)) : (a.y >> (8 * (j - 4)))) & 0xff;
+          if (aj == code && (!relu || ov[j] > 0.f)) g[j] += d[j];
+        }
+      }
+    }
+  }
+};
+
+// partial[grid][3][C]: sum g, sum g*xhat1, sum g*xhat2 (third only if y2)
+template <typename G>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(G gp, const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const bf16_t* __restrict__ y2,
+                                                                   const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                                   int M, int C, float* __restrict__ partial) {
+  const int CV = C >> 3, RL = EW_THREADS / CV;
+  const int cv = threadIdx.x % CV, rl = threadIdx.x / CV;
+  float acc[3][8] = {};
+  float mu[8], rs[8], mu2[8], rs2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = mean[cv * 8 + j]; rs[j] = rstd[cv * 8 + j];
+    mu2[j] = y2 ? mean2[cv * 8 + j] : 0.f; rs2[j] = y2 ? rstd2[cv * 8 + j] : 0.f;
+  }
+  for (int r = blockIdx.x * RL + rl; r < M; r += gridDim.x * RL) {
+    float g[8], v[8];
+    gp.load((size_t)r, cv, g);
+    unpack_bf8(ld16(y + (size_t)r * C + cv * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[0][j] += g[j]; acc[1][j] += g[j] * ((v[j] - mu[j]) * rs[j]); }
+    if (y2) {
+      unpack_bf8(ld16(y2 + (size_t)r * C + cv * 8), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[2][j] += g[j] * ((v[j] - mu2[j]) * rs2[j]);
+    }
+  }
+  block_reduce_store<3>(acc, C, partial);
+}
+
+// backward finalize: dgamma = sum g*xhat, dbeta = sum g (written to the flat gradient buffer), and the two per-channel
+// constants of the apply pass k1 = dbeta / M, k2 = dgamma / M.  which = 1 (main branch) or 2 (shortcut BN, uses quantity 2).
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, int C, int which, float count,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ k1, float* __restrict__ k2) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+  if (c >= C) return;
+  __shared__ double red[2][32][33];
+  double s = 0.0, q = 0.0;
+  for (int p = ry; p < P; p += 32) {
+    s += (double)partial[((size_t)p * 3 + 0) * C + c];
+    q += (double)partial[((size_t)p * 3 + which) * C + c];
+  }
+  red[0][ry][threadIdx.x & 31] = s;
+  red[1][ry][threadIdx.x & 31] = q;
+  __syncthreads();
+  if (ry == 0) {
+    s = 0.0; q = 0.0;
+    for (int r = 0; r < 32; ++r) { s += red[0][r][threadIdx.x & 31]; q += red[1][r][threadIdx.x & 31]; }
+    if (dgamma) dgamma[c] = (float)q;
+    if (dbeta) dbeta[c] = (float)s;
+    k1[c] = (float)(s / (double)count);
+    k2[c] = (float)(q / (double)count);
+  }
+}
+
+// dy = a * (g - k1 - xhat * k2), a = gamma * rstd  (a == nullptr: dy = g, no BN);  optional second BN branch (y2 ...);
+// optional dres (=|+=) g.
+template <typename G>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf16_t* __restrict__ y, const float* __restrict__ a1,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ k1, const float* __restrict__ k2,
+                                                                  bf16_t* __restrict__ dy, int acc_dy,
+                                                                  const bf16_t* __restrict__ y2, const float* __restrict__ a2,
+                                                                  const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                                  const float* __restrict__ k1b, const float* __restrict__ k2b,
+                                                                  bf16_t* __restrict__ dy2, bf16_t* __restrict__ dres, int acc_dres,
+                                                                  size_t M, int C) {
+  const int CV = C >> 3;
+  const size_t total = M * CV;
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_THREADS) {
+    const int cv = (int)(i % CV);
+    const size_t row = i / CV;
+    const int c = cv * 8;
+    float g[8], v[8], o[8];
+    gp.load(row, cv, g);
+    if (dy) {
+      if (a1) {
+        unpack_bf8(ld16(y + i * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = a1[c + j] * (g[j] - k1[c + j] - (v[j] - mean[c + j]) * rstd[c + j] * k2[c + j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = g[j];
+      }
+      if (acc_dy) {
+        unpack_bf8(ld16(dy + i * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += v[j];
+      }
+      st16(dy + i * 8, pack_bf8(o));
+    }
+    if (dy2) {
+      unpack_bf8(ld16(y2 + i * 8), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = a2[c + j] * (g[j] - k1b[c + j] - (v[j] - mean2[c + j]) * rstd2[c + j] * k2b[c + j]);
+      st16(dy2 + i * 8, pack_bf8(o));
+    }
+    if (dres) {
+      if (acc_dres) {
+        unpack_bf8(ld16(dres + i * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += v[j];
+      }
+      st16(dres + i * 8, pack_bf8(g));
+    }
+  }
+}
+
+// ---- gradient split of concat(upsample2x(a[N,H/2,W/2,C0]), b[N,H,W,C1]) given dcat[N,H,W,C0+C1] ----
+__global__ __launch_bounds__(EW_THREADS) void upcat_split_kernel(const bf16_t* __restrict__ dcat, bf16_t* __restrict__ da, int acc_a,
+                                                                 bf16_t* __restrict__ db, int acc_b, int N, int H, int W, int C0, int C1) {
+  const int C = C0 + C1, CV0 = C0 >> 3, CV1 = C1 >> 3;
+  const int H2 = H >> 1, W2 = W >> 1;
+  const size_t na = (size_t)N * H2 * W2 * CV0, nb = (size_t)N * H * W * CV1;
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * EW_THREADS) {
+    float s[8], v[8];
+    if (i < na) {
+      const int cv = (int)(i % CV0);
+      size_t pix = i / CV0;
+      const int w2 = (int)(pix % W2); pix /= W2;
+      const int h2 = (int)(pix % H2);
+      const int n = (int)(pix / H2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+          unpack_bf8(ld16(dcat + ((size_t)(n * H + 2 * h2 + dh) * W + 2 * w2 + dw) * C + cv * 8), v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s[j] += v[j];
+        }
+      if (acc_a) {
+        unpack_bf8(ld16(da + i * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+      }
+      st16(da + i * 8, pack_bf8(s));
+    } else {
+      const size_t k = i - na;
+      const int cv = (int)(k % CV1);
+      const size_t pix = k / CV1;
+      unpack_bf8(ld16(dcat + pix * C + C0 + cv * 8), s);
+      if (acc_b) {
+        unpack_bf8(ld16(db + k * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+      }
+      st16(db + k * 8, pack_bf8(s));
+    }
+  }
+}
+
+// ---- images float32 NHWC (C = 3) -> bf16 NHWC8 (channels 3..7 zero) ----
+__global__ __launch_bounds__(EW_THREADS) void pack_input_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, size_t npix, int Cimg) {
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < npix; i += (size_t)gridDim.x * EW_THREADS) {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < Cimg; ++c) v[c] = img[i * Cimg + c];
+    st16(out + i * 8, pack_bf8(v));
+  }
+}
+
+inline int ew_grid(size_t items) {
+  size_t b = (items + EW_THREADS - 1) / EW_THREADS;
+  if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride beyond
+  if (b < 1) b = 1;
+  return (int)b;
+}
+inline bool chan_ok(int C) {  // C/8 must divide 256
+  if (C < 8 || C % 8) return false;
+  int cv = C / 8;
+  return cv <= 256 && (256 % cv) == 0;
+}
+inline int reduce_grid(int M, int C) {
+  const int RL = EW_THREADS / (C / 8);
+  int b = (M + RL - 1) / RL;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return b;
+}
+
+}  // namespace
+
+extern "C" int yolo_reduce_rows(int M, int C) { return chan_ok(C) && M > 0 ? reduce_grid(M, C) : YOLO_ERR_INVALID_ARG; }
+
+extern "C" int yolo_bn_stats(const void* x, int M, int C, float* partial, void* stream) {
+  YOLO_CHECK_ARG(x && partial && M > 0 && chan_ok(C), "bad argument");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(reduce_grid(M, C)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x, M, C, partial);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_finalize(const float* psum, const float* psq, int P, int64_t row_stride, int C, float count,
+                                const float* gamma, const float* beta, float eps, float momentum, float* moving_mean,
+                                float* moving_var, float* scale, float* shift, float* mean, float* rstd, void* stream) {
+  YOLO_CHECK_ARG(psum && psq && scale && shift && mean && rstd && P > 0 && C > 0 && C % 32 == 0 && count > 0.f, "bad argument");
+  YOLO_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "moving_mean and moving_var go together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 32), dim3(1024), 0, (hipStream_t)stream, psum, psq, P, (size_t)row_stride, C, count,
+                     gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+                               const float* res_shift, void* out, int64_t M, int C, int relu, void* stream) {
+  YOLO_CHECK_ARG(y && out && M > 0 && C > 0 && C % 8 == 0, "bad argument");
+  YOLO_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (res_scale == nullptr) == (res_shift == nullptr), "scale/shift pairs");
+  YOLO_CHECK_ARG(!res_scale || res, "res_scale needs res");
+  const size_t nch = (size_t)M * (C / 8);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, scale, shift,
+                     (const bf16_t*)res, res_scale, res_shift, (bf16_t*)out, nch, C, relu);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_pool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax, int N, int H, int W,
+                                int C, int Ho, int Wo, int pad_t, int pad_l, int relu, void* stream) {
+  YOLO_CHECK_ARG(y && out && argmax && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bad argument");
+  YOLO_CHECK_ARG((scale == nullptr) == (shift == nullptr), "scale/shift pair");
+  YOLO_CHECK_ARG(Ho > 0 && Wo > 0 && (Ho - 1) * 2 - pad_t < H && (Wo - 1) * 2 - pad_l < W && pad_t >= 0 && pad_t < 3 && pad_l >= 0 && pad_l < 3,
+                 "bad pooling geometry");
+  const size_t n = (size_t)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, scale, shift,
+                     (bf16_t*)out, argmax, N, H, W, C, Ho, Wo, pad_t, pad_l, relu);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_act_bwd_reduce(const void* dout, const void* out, int relu, const void* y, const float* mean, const float* rstd,
+                                      const void* y2, const float* mean2, const float* rstd2, int M, int C, float* partial, void* stream) {
+  YOLO_CHECK_ARG(dout && y && mean && rstd && partial && M > 0 && chan_ok(C), "bad argument");
+  YOLO_CHECK_ARG(!relu || out, "relu needs out");
+  YOLO_CHECK_ARG(!y2 || (mean2 && rstd2), "y2 needs mean2/rstd2");
+  PlainGrad gp{(const bf16_t*)dout, (const bf16_t*)out, relu, C};
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<PlainGrad>, dim3(reduce_grid(M, C)), dim3(EW_THREADS), 0, (hipStream_t)stream, gp,
+                     (const bf16_t*)y, mean, rstd, (const bf16_t*)y2, mean2, rstd2, M, C, partial);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_bwd_finalize(const float* partial, int P, int C, int which, float count, float* dgamma, float* dbeta, float* k1,
+                                    float* k2, void* stream) {
+  YOLO_CHECK_ARG(partial && k1 && k2 && P > 0 && C > 0 && C % 32 == 0 && (which == 1 || which == 2) && count > 0.f, "bad argument");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32), dim3(1024), 0, (hipStream_t)stream, partial, P, C, which, count, dgamma, dbeta,
+                     k1, k2);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu, const void* y, const float* a1, const float* mean,
+                                     const float* rstd, const float* k1, const float* k2, void* dy, int acc_dy, const void* y2,
+                                     const float* a2, const float* mean2, const float* rstd2, const float* k1b, const float* k2b,
+                                     void* dy2, void* dres, int acc_dres, int64_t M, int C, void* stream) {
+  YOLO_CHECK_ARG(dout && M > 0 && C > 0 && C % 8 == 0 && (dy || dy2 || dres), "bad argument");
+  YOLO_CHECK_ARG(!relu || out, "relu needs out");
+  YOLO_CHECK_ARG(!a1 || (y && mean && rstd && k1 && k2 && dy), "main BN branch incomplete");
+  YOLO_CHECK_ARG(!dy2 || (y2 && a2 && mean2 && rstd2 && k1b && k2b), "second BN branch incomplete");
+  PlainGrad gp{(const bf16_t*)dout, (const bf16_t*)out, relu, C};
+  const size_t n = (size_t)M * (C / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<PlainGrad>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, gp, (const bf16_t*)y, a1,
+                     mean, rstd, k1, k2, (bf16_t*)dy, acc_dy, (const bf16_t*)y2, a2, mean2, rstd2, k1b, k2b, (bf16_t*)dy2, (bf16_t*)dres,
+                     acc_dres, (size_t)M, C);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+static int pool_grad(PoolGrad* g, const void* dout, const void* out, const uint8_t* argmax, int relu, int N, int H, int W, int C, int Ho,
+                     int Wo, int pad_t, int pad_l) {
+  YOLO_CHECK_ARG(dout && argmax && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && chan_ok(C), "bad argument");
+  YOLO_CHECK_ARG(!relu || out, "relu needs out");
+  *g = PoolGrad{(const bf16_t*)dout, (const bf16_t*)out, argmax, relu, C, H, W, Ho, Wo, pad_t, pad_l};
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_pool_bwd_reduce(const void* dout, const void* out, const uint8_t* argmax, int relu, const void* y, const float* mean,
+                                       const float* rstd, int N, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, float* partial,
+                                       void* stream) {
+  PoolGrad gp;
+  int rc = pool_grad(&gp, dout, out, argmax, relu, N, H, W, C, Ho, Wo, pad_t, pad_l);
+  if (rc) return rc;
+  YOLO_CHECK_ARG(y && mean && rstd && partial, "null pointer");
+  const int M = N * H * W;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<PoolGrad>, dim3(reduce_grid(M, C)), dim3(EW_THREADS), 0, (hipStream_t)stream, gp, (const bf16_t*)y,
+                     mean, rstd, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, partial);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_pool_bwd_apply(const void* dout, const void* out, const uint8_t* argmax, int relu, const void* y, const float* a1,
+                                      const float* mean, const float* rstd, const float* k1, const float* k2, void* dy, int N, int H, int W,
+                                      int C, int Ho, int Wo, int pad_t, int pad_l, void* stream) {
+  PoolGrad gp;
+  int rc = pool_grad(&gp, dout, out, argmax, relu, N, H, W, C, Ho, Wo, pad_t, pad_l);
+  if (rc) return rc;
+  YOLO_CHECK_ARG(dy, "null dy");
+  YOLO_CHECK_ARG(!a1 || (y && mean && rstd && k1 && k2), "BN branch incomplete");
+  const size_t M = (size_t)N * H * W;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<PoolGrad>, dim3(ew_grid(M * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream, gp,
+                     (const bf16_t*)y, a1, mean, rstd, k1, k2, (bf16_t*)dy, 0, (const bf16_t*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr,
+                     (bf16_t*)nullptr, 0, M, C);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_upcat_split_bwd(const void* dcat, void* da, int acc_a, void* db, int acc_b, int N, int H, int W, int C0, int C1,
+                                    void* stream) {
+  YOLO_CHECK_ARG(dcat && da && db && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C0 > 0 && C1 > 0 && C0 % 8 == 0 && C1 % 8 == 0,
+                 "bad argument");
+  const size_t n = (size_t)N * (H / 2) * (W / 2) * (C0 / 8) + (size_t)N * H * W * (C1 / 8);
+  hipLaunchKernelGGL(upcat_split_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)dcat, (bf16_t*)da, acc_a,
+                     (bf16_t*)db, acc_b, N, H, W, C0, C1);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_pack_input(const float* images, void* out, int64_t npix, int Cimg, void* stream) {
+  YOLO_CHECK_ARG(images && out && npix > 0 && Cimg > 0 && Cimg <= 8, "bad argument");
+  hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)npix)), dim3(EW_THREADS), 0, (hipStream_t)stream, images, (bf16_t*)out,
+                     (size_t)npix, Cimg);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}

@@ -1,0 +1,361 @@
+// YOLOv3 loss forward + backward on gfx950, float32 throughout (compiled with -ffp-contract=off so the IoU / BCE
+// arithmetic keeps the reference's operation order).
+//
+// Replaces, for the training step, yolov3/yolov3_decoder.py:119-192 (decode), yolov3/label_decoder.py:44-60 and
+// yolov3/yolov3_loss.py:81-369 (IoU assignment, masks, xy/wh/conf/class terms, rectified prior loss) plus the TF autodiff of
+// that graph, and removes the reference's sequential per-image tf.map_fn (yolov3_loss.py:111): every prediction of every image
+// is one lane.
+//
+// Launch sequence of yolo_loss_fwd_bwd (all on the caller's stream):
+//   1. assign  : one workgroup per image; per (GT, head) the response cell, the IoU of its B predicted boxes with the GT, the
+//                first arg-max anchor (yolov3_loss.py:269-302) and the cross-head ">=" selection (:203-208).
+//   2. main    : one lane per prediction: decode, max IoU over the image's GTs (:275-294), object / background masks
+//                (:328-332), every loss term this prediction takes part in and the COMPLETE gradient of its L logits;
+//                wave-cooperative coalesced stores of d(logits) (float32 and/or bf16); 6 block partial sums.
+//   3. finalize: batch mean -> terms[6][3] (rows xy, wh, noobj, obj, class, rectified; columns /8,/16,/32), total, and the
+//                rectified-image counter update (:125-130,152).
+#include "common.h"
+
+namespace {
+
+struct LossCfg {
+  yolo_loss_config c;
+  int P[3];       // predictions per image per head = H*W*B
+  float area[3];  // H*W as float
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float clipf_(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// IoU of a predicted corner box with a GT corner box, in the reference's operation order (yolov3_loss.py:276-293)
+__device__ __forceinline__ float iou_ref(float px0, float py0, float px1, float py1, float parea, float tx0, float ty0, float tx1,
+                                         float ty1, float tarea, int tiou) {
+  const float iw = fmaxf(fminf(px1, tx1) - fmaxf(px0, tx0), 0.f);
+  const float ih = fmaxf(fminf(py1, ty1) - fmaxf(py0, ty0), 0.f);
+  const float inter = iw * ih;
+  float iou = inter / (parea + tarea - inter);
+  if (tiou) iou = iou * inter / tarea;
+  return iou;
+}
+
+struct Box { float x0, y0, x1, y1, area, w, h, cx, cy; };
+
+__device__ __forceinline__ Box decode_box(const float* t, int col, int row, float aw, float ah, float eps_lo, float eps_hi) {
+  Box b;
+  b.cx = clipf_(sigmoidf_(t[0]), eps_lo, eps_hi) + (float)col;  // yolov3_decoder.py:153-155
+  b.cy = clipf_(sigmoidf_(t[1]), eps_lo, eps_hi) + (float)row;
+  b.w = expf(t[2]) * aw;                                         // :167-168
+  b.h = expf(t[3]) * ah;
+  const float hw = b.w / 2, hh = b.h / 2;
+  b.x0 = b.cx - hw; b.y0 = b.cy - hh; b.x1 = b.cx + hw; b.y1 = b.cy + hh;  // :137-139
+  b.area = b.w * b.h;                                            // yolov3_loss.py:267
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- 1. assign
+__global__ __launch_bounds__(64) void loss_assign_kernel(LossCfg cfg, const float* __restrict__ l0, const float* __restrict__ l1,
+                                                         const float* __restrict__ l2, const float* __restrict__ labels,
+                                                         int* __restrict__ assign /*[N][T][3]*/, float* __restrict__ resp_iou /*[N][T][3]*/) {
+  extern __shared__ float sh[];  // [T][3] response IoU, then [T][3] prediction index (as int)
+  const yolo_loss_config& c = cfg.c;
+  const int n = blockIdx.x, T = c.T;
+  float* s_iou = sh;
+  int* s_idx = reinterpret_cast<int*>(sh + T * 3);
+  const float eps_lo = c.eps, eps_hi = 1.f - c.eps;
+  for (int k = threadIdx.x; k < T * 3; k += blockDim.x) {
+    const int t = k / 3, h = k - t * 3;
+    const float* lab = labels + ((size_t)n * T + t) * 5;
+    float best = -INFINITY;
+    int bidx = -1;
+    if (lab[0] >= 0.f) {  // yolov3_loss.py:239
+      const int H = c.H[h], W = c.W[h], B = c.B[h];
+      const float tx = lab[0] * (float)W, ty = lab[1] * (float)H;  // label_decoder.py:53
+      const float tw = lab[2] * (float)W, th = lab[3] * (float)H;  // :54
+      const float thw = tw / 2, thh = th / 2;
+      const float tx0 = tx - thw, ty0 = ty - thh, tx1 = tx + thw, ty1 = ty + thh;  // :58-59
+      const float tarea = tw * th;                                                 // yolov3_loss.py:273
+      int col = (int)floorf(tx), row = (int)floorf(ty);                           // :269-270
+      col = min(max(col, 0), W - 1);  // documented divergence: clamp instead of a failing gather_nd
+      row = min(max(row, 0), H - 1);
+      const float* base = (h == 0 ? l0 : (h == 1 ? l1 : l2)) + ((size_t)(n * H + row) * W + col) * c.ldc[h];
+      int barg = 0;
+      for (int b = 0; b < B; ++b) {
+        const Box p = decode_box(base + b * c.L, col, row, c.anchor_w[h][b], c.anchor_h[h][b], eps_lo, eps_hi);
+        const float v = iou_ref(p.x0, p.y0, p.x1, p.y1, p.area, tx0, ty0, tx1, ty1, tarea, c.is_tiou_recall);
+        if (b == 0 || v > best) { best = v; barg = b; }  // first maximum (tf.arg_max)
+      }
+      bidx = (row * W + col) * B + barg;
+    }
+    s_iou[k] = best;
+    s_idx[k] = bidx;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float i0 = s_iou[t * 3], i1 = s_iou[t * 3 + 1], i2 = s_iou[t * 3 + 2];
+    const bool valid = s_idx[t * 3] >= 0;
+    const bool a0 = valid && i0 >= i1 && i0 >= i2;  // yolov3_loss.py:203-208 (ties go to several heads)
+    const bool a1 = valid && i1 >= i0 && i1 >= i2;
+    const bool a2 = valid && i2 >= i0 && i2 >= i1;
+    int* o = assign + ((size_t)n * T + t) * 3;
+    o[0] = a0 ? s_idx[t * 3] : -1;
+    o[1] = a1 ? s_idx[t * 3 + 1] : -1;
+    o[2] = a2 ? s_idx[t * 3 + 2] : -1;
+    if (resp_iou) {
+      float* r = resp_iou + ((size_t)n * T + t) * 3;
+      r[0] = i0; r[1] = i1; r[2] = i2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- 2. main
+constexpr int LM_THREADS = 256;
+
+__global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, const float* __restrict__ l0, const float* __restrict__ l1,
+                                                               const float* __restrict__ l2, const float* __restrict__ labels,
+                                                               const int* __restrict__ assign, const int* __restrict__ current_num,
+                                                               float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2,
+                                                               bf16_t* __restrict__ e0, bf16_t* __restrict__ e1, bf16_t* __restrict__ e2,
+                                                               float* __restrict__ partial /*[N][3][gridDim.x][6]*/, float inv_n) {
+  extern __shared__ float sh[];
+  const yolo_loss_config& c = cfg.c;
+  const int h = blockIdx.y, n = blockIdx.z, T = c.T, L = c.L;
+  const int H = c.H[h], W = c.W[h], B = c.B[h], ldc = c.ldc[h], P = cfg.P[h];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // LDS: GT table [T][8] (x0,y0,x1,y1,area,valid,-,-), assignment [T], wave scratch [4][64][5], reduction [4][6]
+  float* s_gt = sh;
+  int* s_as = reinterpret_cast<int*>(sh + T * 8);
+  float* s_w = sh + T * 9 + wave * 64 * 5;
+  float* s_red = sh + T * 9 + 4 * 64 * 5;
+  const float fW = (float)W, fH = (float)H;
+  for (int t = threadIdx.x; t < T; t += LM_THREADS) {
+    const float* lab = labels + ((size_t)n * T + t) * 5;
+    const float tx = lab[0] * fW, ty = lab[1] * fH, tw = lab[2] * fW, th = lab[3] * fH;
+    const float thw = tw / 2, thh = th / 2;
+    s_gt[t * 8 + 0] = tx - thw; s_gt[t * 8 + 1] = ty - thh; s_gt[t * 8 + 2] = tx + thw; s_gt[t * 8 + 3] = ty + thh;
+    s_gt[t * 8 + 4] = tw * th;
+    s_gt[t * 8 + 5] = lab[0] >= 0.f ? 1.f : 0.f;
+    s_as[t] = assign[((size_t)n * T + t) * 3 + h];
+  }
+  __syncthreads();
+
+  const float* lg = (h == 0 ? l0 : (h == 1 ? l1 : l2)) + (size_t)n * H * W * ldc;
+  float* dg = (h == 0 ? d0 : (h == 1 ? d1 : d2));
+  bf16_t* eg = (h == 0 ? e0 : (h == 1 ? e1 : e2));
+  if (dg) dg += (size_t)n * H * W * ldc;
+  if (eg) eg += (size_t)n * H * W * ldc;
+  const bool rect = c.rectified_coord_num >= 0 && current_num[0] <= c.rectified_coord_num;  // yolov3_loss.py:125
+  const float eps_lo = c.eps, eps_hi = 1.f - c.eps;
+  const float w_xy = c.w_xy[h], w_wh = c.w_wh[h], w_no = c.w_noobj[h], w_obj = c.w_obj[h], w_cls = c.w_cls[h], w_r = c.w_rect[h];
+
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // xy, wh, noobj, obj, class, rectified (un-normalised sums)
+  const int wave_base = (blockIdx.x * (LM_THREADS / 64) + wave) * 64;
+  if (wave_base < P) {  // wave-uniform
+    const int pid = wave_base + lane;
+    const bool pv = pid < P;
+    float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int nresp = 0;
+    int cell = 0, b = 0;
+    const float* t = lg;
+    if (pv) {
+      cell = pid / B; b = pid - cell * B;
+      const int row = cell / W, col = cell - row * W;
+      t = lg + (size_t)cell * ldc + b * L;
+      const float t4[5] = {t[0], t[1], t[2], t[3], t[4]};
+      const float aw = c.anchor_w[h][b], ah = c.anchor_h[h][b];
+      const Box p = decode_box(t4, col, row, aw, ah, eps_lo, eps_hi);
+      const float sx = sigmoidf_(t4[0]), sy = sigmoidf_(t4[1]);
+      const float sc = sigmoidf_(t4[4]);
+      const float conf = clipf_(sc, eps_lo, eps_hi);          // yolov3_decoder.py:178-179
+      const bool conf_pass = sc >= eps_lo && sc <= eps_hi;    // tf.clip_by_value gradient
+      float max_iou = -INFINITY;
+      for (int k = 0; k < T; ++k) {
+        if (s_gt[k * 8 + 5] == 0.f) continue;
+        const float v = iou_ref(p.x0, p.y0, p.x1, p.y1, p.area, s_gt[k * 8], s_gt[k * 8 + 1], s_gt[k * 8 + 2], s_gt[k * 8 + 3],
+                                s_gt[k * 8 + 4], c.is_tiou_recall);
+        max_iou = fmaxf(max_iou, v);                          // yolov3_loss.py:294
+        if (s_as[k] == pid) {                                 // this prediction is responsible for GT k (:341-342)
+          ++nresp;
+          const float* lab = labels + ((size_t)n * T + k) * 5;
+          const float tx = lab[0] * fW, ty = lab[1] * fH, tw = lab[2] * fW, th = lab[3] * fH;
+          // obj (:344-347)
+          float lo = -logf(conf), go;
+          if (c.is_focal_loss) {
+            const float om = 1.f - conf;
+            lo = lo * (powf(om, c.focal_gamma) * c.focal_alpha);
+            go = c.focal_alpha * (-powf(om, c.focal_gamma) / conf + c.focal_gamma * powf(om, c.focal_gamma - 1.f) * logf(conf)) * (sc * (1.f - sc));
+          } else {
+            go = -(1.f / conf) * (sc * (1.f - sc));
+          }
+          acc[3] += lo;
+          if (conf_pass) g[4] += w_obj * go;
+          // xy / wh (:350-359)
+          const float scale = 2.f - tw * th / cfg.area[h];
+          const float cix = floorf(tx), ciy = floorf(ty);
+          const float txf = tx - cix, tyf = ty - ciy;
+          const float pxf = p.cx - cix, pyf = p.cy - ciy;
+          acc[0] += scale * (-(txf * logf(pxf) + (1.f - txf) * logf(1.f - pxf))) + scale * (-(tyf * logf(pyf) + (1.f - tyf) * logf(1.f - pyf)));
+          if (sx >= eps_lo && sx <= eps_hi) g[0] += w_xy * scale * (-txf / pxf + (1.f - txf) / (1.f - pxf)) * (sx * (1.f - sx));
+          if (sy >= eps_lo && sy <= eps_hi) g[1] += w_xy * scale * (-tyf / pyf + (1.f - tyf) / (1.f - pyf)) * (sy * (1.f - sy));
+          const float dw_ = logf(tw) - logf(p.w), dh_ = logf(th) - logf(p.h);
+          acc[1] += scale * (dw_ * dw_) + scale * (dh_ * dh_);
+          g[2] += w_wh * scale * (-2.f * dw_);
+          g[3] += w_wh * scale * (-2.f * dh_);
+        }
+      }
+      // background (:331-338)
+      if (nresp == 0 && max_iou < c.iou_thresh) {
+        float ln = -logf(1.f - conf), gn;
+        if (c.is_focal_loss) {
+          ln = ln * powf(conf, c.focal_gamma);
+          gn = (powf(conf, c.focal_gamma) / (1.f - conf) - c.focal_gamma * powf(conf, c.focal_gamma - 1.f) * logf(1.f - conf)) * (sc * (1.f - sc));
+        } else {
+          gn = (1.f / (1.f - conf)) * (sc * (1.f - sc));
+        }
+        acc[2] += ln;
+        if (conf_pass) g[4] += w_no * gn;
+      }
+      if (rect) {  // yolov3_loss.py:153-162
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[5] += t4[j] * t4[j]; g[j] += w_r * 2.f * t4[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) g[j] *= inv_n;
+    }
+    // ---- wave-cooperative store of the 64 x L gradient block ----
+#pragma unroll
+    for (int j = 0; j < 5; ++j) s_w[lane * 5 + j] = g[j];
+    const unsigned long long rmask = __ballot(nresp > 0 && L > 5);
+    // (same-wave LDS write -> read: no barrier needed, but keep the compiler from reordering)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = min(64, P - wave_base) * L;
+    for (int i = lane; i < cnt; i += 64) {
+      const int pl = i / L, j = i - pl * L;
+      const int id = wave_base + pl;
+      const int cl = id / B, bb = id - cl * B;
+      const size_t off = (size_t)cl * ldc + bb * L + j;
+      float v = 0.f;
+      if (j < 5) v = s_w[pl * 5 + j];
+      else if ((rmask >> pl) & 1ull) continue;  // class gradients of responsible predictions are written by their own lane
+      if (dg) dg[off] = v;
+      if (eg) eg[off] = f2bf(v);
+    }
+    // ---- class term of responsible predictions (:361-364) ----
+    if (pv && nresp > 0 && L > 5) {
+      const int C = L - 5;
+      float mx = -INFINITY;
+      for (int k = 0; k < C; ++k) mx = fmaxf(mx, t[5 + k]);
+      float se = 0.f;
+      for (int k = 0; k < C; ++k) se += expf(t[5 + k] - mx);
+      for (int k = 0; k < T; ++k) {
+        if (s_as[k] != pid) continue;
+        const int cls = (int)labels[((size_t)n * T + k) * 5 + 4];
+        if (cls >= 0 && cls < C) {
+          const float pr = clipf_(expf(t[5 + cls] - mx) / se, eps_lo, eps_hi);
+          acc[4] += -logf(pr);
+        }
+      }
+      const size_t off0 = (size_t)cell * ldc + b * L + 5;
+      for (int k = 0; k < C; ++k) {
+        const float sm = expf(t[5 + k] - mx) / se;
+        float gk = 0.f;
+        for (int q = 0; q < T; ++q) {
+          if (s_as[q] != pid) continue;
+          const int cls = (int)labels[((size_t)n * T + q) * 5 + 4];
+          if (cls < 0 || cls >= C) continue;
+          const float pc = expf(t[5 + cls] - mx) / se;
+          if (pc >= eps_lo && pc <= eps_hi) gk += sm - (k == cls ? 1.f : 0.f);
+        }
+        gk *= w_cls * inv_n;
+        if (dg) dg[off0 + k] = gk;
+        if (eg) eg[off0 + k] = f2bf(gk);
+      }
+    }
+  }
+  // ---- block partial sums (un-weighted sums; weights and 1/N applied in finalize) ----
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) s_red[wave * 6 + k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const float s = s_red[threadIdx.x] + s_red[6 + threadIdx.x] + s_red[12 + threadIdx.x] + s_red[18 + threadIdx.x];
+    partial[(((size_t)n * 3 + h) * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- 3. finalize
+__global__ __launch_bounds__(64) void loss_finalize_kernel(LossCfg cfg, const float* __restrict__ partial, int N, int nbx, float inv_n,
+                                                           int batch_global, int* __restrict__ current_num, float* __restrict__ terms /*[6][3]*/,
+                                                           float* __restrict__ total) {
+  __shared__ float s_t[18];
+  const yolo_loss_config& c = cfg.c;
+  const bool rect = c.rectified_coord_num >= 0 && current_num[0] <= c.rectified_coord_num;
+  if (threadIdx.x < 18) {
+    const int k = threadIdx.x / 3, h = threadIdx.x - k * 3;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {  // per-image sums first (the reference reduces per image, then means over the batch)
+      float si = 0.f;
+      for (int b = 0; b < nbx; ++b) si += partial[(((size_t)n * 3 + h) * nbx + b) * 6 + k];
+      s += si;
+    }
+    const float w = (k == 0 ? c.w_xy[h] : k == 1 ? c.w_wh[h] : k == 2 ? c.w_noobj[h] : k == 3 ? c.w_obj[h] : k == 4 ? c.w_cls[h] : c.w_rect[h]);
+    float v = w * s * inv_n;
+    if (k == 5 && !rect) v = 0.f;
+    s_t[threadIdx.x] = v;
+    terms[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 18; ++i) s += s_t[i];
+    total[0] = s;
+    if (rect) current_num[0] += batch_global;  // yolov3_loss.py:152 (advances only while the rectified branch is taken)
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t yolo_loss_workspace_bytes(const yolo_loss_config* c, int N) {
+  if (!c || N <= 0 || c->T <= 0) return YOLO_ERR_INVALID_ARG;
+  int maxP = 0;
+  for (int h = 0; h < 3; ++h) maxP = maxP > c->H[h] * c->W[h] * c->B[h] ? maxP : c->H[h] * c->W[h] * c->B[h];
+  const int nbx = (maxP + LM_THREADS - 1) / LM_THREADS;
+  return (int64_t)N * c->T * 3 * 4 /*assign*/ + (int64_t)N * 3 * nbx * 6 * 4 /*partials*/;
+}
+
+extern "C" int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_global, const float* logits8, const float* logits16,
+                                 const float* logits32, const float* labels, float* dlogits8, float* dlogits16, float* dlogits32,
+                                 void* dlogits8_bf16, void* dlogits16_bf16, void* dlogits32_bf16, int* current_num, float* terms,
+                                 float* total, int* assign_out, float* resp_iou_out, void* workspace, void* stream) {
+  YOLO_CHECK_ARG(c && N > 0 && batch_global >= N, "bad config / batch");
+  YOLO_CHECK_ARG(logits8 && logits16 && logits32 && labels && current_num && terms && total && workspace, "null pointer");
+  YOLO_CHECK_ARG(c->T > 0 && c->T <= 512 && c->L >= 5 && c->L <= 4096, "bad T / L");
+  LossCfg cfg;
+  cfg.c = *c;
+  int maxP = 0;
+  for (int h = 0; h < 3; ++h) {
+    YOLO_CHECK_ARG(c->H[h] > 0 && c->W[h] > 0 && c->B[h] > 0 && c->B[h] <= YOLO_MAX_ANCHORS, "bad head geometry");
+    YOLO_CHECK_ARG(c->ldc[h] >= c->B[h] * c->L, "ldc smaller than B*L");
+    cfg.P[h] = c->H[h] * c->W[h] * c->B[h];
+    cfg.area[h] = (float)(c->H[h] * c->W[h]);
+    maxP = maxP > cfg.P[h] ? maxP : cfg.P[h];
+  }
+  const int nbx = (maxP + LM_THREADS - 1) / LM_THREADS;
+  int* assign = assign_out ? assign_out : reinterpret_cast<int*>(workspace);
+  float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (size_t)N * c->T * 3 * 4);
+  hipStream_t st = (hipStream_t)stream;
+  const float inv_n = 1.f / (float)N;
+  hipLaunchKernelGGL(loss_assign_kernel, dim3(N), dim3(64), (size_t)c->T * 3 * 2 * 4, st, cfg, logits8, logits16, logits32, labels, assign,
+                     resp_iou_out);
+  YOLO_LAUNCH_CHECK();
+  const size_t lds = ((size_t)c->T * 9 + 4 * 64 * 5 + 4 * 6) * 4;
+  hipLaunchKernelGGL(loss_main_kernel, dim3(nbx, 3, N), dim3(LM_THREADS), lds, st, cfg, logits8, logits16, logits32, labels, assign,
+                     current_num, dlogits8, dlogits16, dlogits32, (bf16_t*)dlogits8_bf16, (bf16_t*)dlogits16_bf16, (bf16_t*)dlogits32_bf16,
+                     partial, inv_n);
+  YOLO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, cfg, partial, N, nbx, inv_n, batch_global, current_num, terms, total);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}

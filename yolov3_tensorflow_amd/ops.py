@@ -1,0 +1,195 @@
+"""Thin torch-tensor wrappers over the C-ABI (pointers + current HIP stream).  PyTorch is only the allocator / stream
+provider here; every computation is a kernel of libyolov3_amd.so.  No fallback paths.
+"""
+import ctypes as C
+import numpy as np
+import torch
+from . import _lib
+from ._lib import ConvProblem, LossConfig, check
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def same_pad(size, k, s):
+    """TF 'same' padding: (out, pad_before)"""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2
+
+
+def conv_problem(N, H, W, Cin, Cout, k=3, stride=1, padding='same', C0=0):
+    if padding == 'same':
+        Ho, pt = same_pad(H, k, stride)
+        Wo, pl = same_pad(W, k, stride)
+    else:
+        Ho, Wo, pt, pl = (H - k) // stride + 1, (W - k) // stride + 1, 0, 0
+    return ConvProblem(N, H, W, Cin, C0, Cout, k, k, stride, pt, pl, Ho, Wo)
+
+
+def pad_channels(c):
+    """detection-conv output channels are padded to 64 * 2^k (GEMM tile and power-of-two k-chunk constraints)"""
+    p = 64
+    while p < c:
+        p *= 2
+    return p
+
+
+def conv2d_stat_rows(p):
+    r = _lib.load().yolo_conv2d_stat_rows(C.byref(p))
+    if r < 0:
+        raise _lib.YoloNativeError('yolo_conv2d_stat_rows rejected the problem')
+    return r
+
+
+def conv2d_fwd(p, src1, w_fwd, y, src0=None, bias=None, stat_sum=None, stat_sq=None):
+    check(_lib.load().yolo_conv2d_fwd(C.byref(p), _p(src0), _p(src1), _p(w_fwd), _p(bias), _p(y),
+                                      1 if y.dtype == torch.float32 else 0, _p(stat_sum), _p(stat_sq), _stream()), 'yolo_conv2d_fwd')
+
+
+def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False):
+    check(_lib.load().yolo_conv2d_dgrad(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _stream()), 'yolo_conv2d_dgrad')
+
+
+def conv2d_wgrad(p, src1, dy, dw, src0=None, split_k=0):
+    check(_lib.load().yolo_conv2d_wgrad(C.byref(p), _p(src0), _p(src1), _p(dy), _p(dw), split_k, _stream()), 'yolo_conv2d_wgrad')
+
+
+def repack_dgrad_weights(w_fwd, w_dgrad, Cout, R, S, Cin):
+    check(_lib.load().yolo_repack_dgrad_weights(_p(w_fwd), _p(w_dgrad), Cout, R, S, Cin, _stream()), 'yolo_repack_dgrad_weights')
+
+
+def reduce_rows(M, Cc):
+    r = _lib.load().yolo_reduce_rows(M, Cc)
+    if r < 0:
+        raise _lib.YoloNativeError('yolo_reduce_rows(%d, %d) rejected' % (M, Cc))
+    return r
+
+
+def bn_stats(x, M, Cc, partial):
+    check(_lib.load().yolo_bn_stats(_p(x), M, Cc, _p(partial), _stream()), 'yolo_bn_stats')
+
+
+def bn_finalize(psum, psq, P, row_stride, Cc, count, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd):
+    check(_lib.load().yolo_bn_finalize(_p(psum), _p(psq), P, row_stride, Cc, float(count), _p(gamma), _p(beta), eps, momentum,
+                                       _p(moving_mean), _p(moving_var), _p(scale), _p(shift), _p(mean), _p(rstd), _stream()),
+          'yolo_bn_finalize')
+
+
+def bn_act_fwd(y, scale, shift, out, M, Cc, relu, res=None, res_scale=None, res_shift=None):
+    check(_lib.load().yolo_bn_act_fwd(_p(y), _p(scale), _p(shift), _p(res), _p(res_scale), _p(res_shift), _p(out), M, Cc, int(relu),
+                                      _stream()), 'yolo_bn_act_fwd')
+
+
+def bn_pool_fwd(y, scale, shift, out, argmax, N, H, W, Cc, Ho, Wo, pt, pl, relu):
+    check(_lib.load().yolo_bn_pool_fwd(_p(y), _p(scale), _p(shift), _p(out), _p(argmax), N, H, W, Cc, Ho, Wo, pt, pl, int(relu),
+                                       _stream()), 'yolo_bn_pool_fwd')
+
+
+def bn_act_bwd_reduce(dout, out, relu, y, mean, rstd, M, Cc, partial, y2=None, mean2=None, rstd2=None):
+    check(_lib.load().yolo_bn_act_bwd_reduce(_p(dout), _p(out), int(relu), _p(y), _p(mean), _p(rstd), _p(y2), _p(mean2), _p(rstd2),
+                                             M, Cc, _p(partial), _stream()), 'yolo_bn_act_bwd_reduce')
+
+
+def bn_bwd_finalize(partial, P, Cc, which, count, dgamma, dbeta, k1, k2):
+    check(_lib.load().yolo_bn_bwd_finalize(_p(partial), P, Cc, which, float(count), _p(dgamma), _p(dbeta), _p(k1), _p(k2), _stream()),
+          'yolo_bn_bwd_finalize')
+
+
+def bn_act_bwd_apply(dout, out, relu, M, Cc, y=None, a1=None, mean=None, rstd=None, k1=None, k2=None, dy=None, acc_dy=False,
+                     y2=None, a2=None, mean2=None, rstd2=None, k1b=None, k2b=None, dy2=None, dres=None, acc_dres=False):
+    check(_lib.load().yolo_bn_act_bwd_apply(_p(dout), _p(out), int(relu), _p(y), _p(a1), _p(mean), _p(rstd), _p(k1), _p(k2), _p(dy),
+                                            int(acc_dy), _p(y2), _p(a2), _p(mean2), _p(rstd2), _p(k1b), _p(k2b), _p(dy2), _p(dres),
+                                            int(acc_dres), M, Cc, _stream()), 'yolo_bn_act_bwd_apply')
+
+
+def bn_pool_bwd_reduce(dout, out, argmax, relu, y, mean, rstd, N, H, W, Cc, Ho, Wo, pt, pl, partial):
+    check(_lib.load().yolo_bn_pool_bwd_reduce(_p(dout), _p(out), _p(argmax), int(relu), _p(y), _p(mean), _p(rstd), N, H, W, Cc, Ho, Wo,
+                                              pt, pl, _p(partial), _stream()), 'yolo_bn_pool_bwd_reduce')
+
+
+def bn_pool_bwd_apply(dout, out, argmax, relu, y, a1, mean, rstd, k1, k2, dy, N, H, W, Cc, Ho, Wo, pt, pl):
+    check(_lib.load().yolo_bn_pool_bwd_apply(_p(dout), _p(out), _p(argmax), int(relu), _p(y), _p(a1), _p(mean), _p(rstd), _p(k1),
+                                             _p(k2), _p(dy), N, H, W, Cc, Ho, Wo, pt, pl, _stream()), 'yolo_bn_pool_bwd_apply')
+
+
+def upcat_split_bwd(dcat, da, acc_a, db, acc_b, N, H, W, C0, C1):
+    check(_lib.load().yolo_upcat_split_bwd(_p(dcat), _p(da), int(acc_a), _p(db), int(acc_b), N, H, W, C0, C1, _stream()),
+          'yolo_upcat_split_bwd')
+
+
+def pack_input(images, out, npix, cimg):
+    check(_lib.load().yolo_pack_input(_p(images), _p(out), npix, cimg, _stream()), 'yolo_pack_input')
+
+
+def make_loss_config(head_grid_sizes, class_num, anchor_boxes, iou_thresh, loss_weights, ldc, T,
+                     rectified_coord_num=0, rectified_loss_weight=None, is_focal_loss=False, focal_alpha=0.25,
+                     focal_gamma=2.0, is_tiou_recall=False, eps=1e-8):
+    c = LossConfig()
+    lw = np.asarray(loss_weights, dtype=np.float32)
+    if rectified_loss_weight is None:
+        rectified_loss_weight = [0.01, 0.01, 0.01]
+    for h in range(3):
+        gh, gw = int(head_grid_sizes[h][0]), int(head_grid_sizes[h][1])
+        c.H[h], c.W[h], c.B[h], c.ldc[h] = gh, gw, len(anchor_boxes[h]), int(ldc[h])
+        if len(anchor_boxes[h]) > _lib.MAX_ANCHORS:
+            raise ValueError('at most %d anchors per head' % _lib.MAX_ANCHORS)
+        for b, (aw, ah) in enumerate(anchor_boxes[h]):
+            c.anchor_w[h][b] = float(np.float32(aw) * np.float32(gw))   # yolov3_decoder.py:38-40, float32 product
+            c.anchor_h[h][b] = float(np.float32(ah) * np.float32(gh))
+        c.w_xy[h], c.w_wh[h], c.w_noobj[h], c.w_obj[h], c.w_cls[h] = [float(v) for v in lw[h]]
+        c.w_rect[h] = float(rectified_loss_weight[h])
+    c.L = 5 + class_num
+    c.T = T
+    c.iou_thresh = iou_thresh
+    c.rectified_coord_num = int(rectified_coord_num)
+    c.is_focal_loss = int(bool(is_focal_loss))
+    c.focal_alpha, c.focal_gamma = focal_alpha, focal_gamma
+    c.is_tiou_recall = int(bool(is_tiou_recall))
+    c.eps = eps
+    return c
+
+
+def loss_workspace_bytes(cfg, N):
+    r = _lib.load().yolo_loss_workspace_bytes(C.byref(cfg), N)
+    if r < 0:
+        raise _lib.YoloNativeError('yolo_loss_workspace_bytes rejected the config')
+    return r
+
+
+def loss_fwd_bwd(cfg, N, batch_global, logits, labels, current_num, terms, total, workspace, dlogits=(None, None, None),
+                 dlogits_bf16=(None, None, None), assign_out=None, resp_iou_out=None):
+    check(_lib.load().yolo_loss_fwd_bwd(C.byref(cfg), N, batch_global, _p(logits[0]), _p(logits[1]), _p(logits[2]), _p(labels),
+                                        _p(dlogits[0]), _p(dlogits[1]), _p(dlogits[2]), _p(dlogits_bf16[0]), _p(dlogits_bf16[1]),
+                                        _p(dlogits_bf16[2]), _p(current_num), _p(terms), _p(total), _p(assign_out), _p(resp_iou_out),
+                                        _p(workspace), _stream()), 'yolo_loss_fwd_bwd')
+
+
+def radam_schedule(sched, iterations, beta1, beta2, decay, warmup_coef):
+    check(_lib.load().yolo_radam_schedule(_p(sched), _p(iterations), beta1, beta2, decay, warmup_coef, _stream()), 'yolo_radam_schedule')
+
+
+def radam_l2_blocks(n):
+    r = _lib.load().yolo_radam_l2_blocks(n)
+    if r < 0:
+        raise _lib.YoloNativeError('yolo_radam_l2_blocks(%d) rejected' % n)
+    return r
+
+
+def radam_l2_step(params, grads, m, v, l2_table, n, sched, beta1, beta2, eps, grad_scale=1.0, zero_grad=True, params_bf16=None,
+                  vhat=None, l2_partial=None):
+    check(_lib.load().yolo_radam_l2_step(_p(params), _p(grads), _p(m), _p(v), _p(vhat), _p(params_bf16), _p(l2_table), n, _p(sched),
+                                         beta1, beta2, eps, grad_scale, int(zero_grad), _p(l2_partial), _stream()), 'yolo_radam_l2_step')
+
+
+def cast_f32_to_bf16(x, y, n):
+    check(_lib.load().yolo_cast_f32_to_bf16(_p(x), _p(y), n, _stream()), 'yolo_cast_f32_to_bf16')
+
+
+def sum_partials(partial, n, add, out):
+    check(_lib.load().yolo_sum_partials(_p(partial), n, _p(add), _p(out), _stream()), 'yolo_sum_partials')
