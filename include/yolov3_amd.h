@@ -41,7 +41,7 @@ typedef struct {
   int32_t N, H, W;     /* input batch and spatial size */
   int32_t Cin;         /* input channels, multiple of 8 and (Cin/8) a power of two (the RGB stem is padded 3 -> 8) */
   int32_t C0;          /* > 0: the input is concat(upsample2x(src0[N,H/2,W/2,C0]), src1[N,H,W,Cin-C0]); 0: src1 only */
-  int32_t Cout;        /* output channels, padded to a multiple of 64 (255 -> 256, 170 -> 192) */
+  int32_t Cout;        /* output channels, padded to 64 * 2^k (255 -> 256, 170 -> 256) */
   int32_t R, S;        /* kernel height / width */
   int32_t stride;      /* 1 or 2 (same in both directions) */
   int32_t pad_t, pad_l;/* top/left zero padding (TF 'same': (0,0) for k=3 s=2 on even sizes, (1,1) for k=3 s=1) */
@@ -105,6 +105,11 @@ int yolo_bn_pool_bwd_apply(const void* dout, const void* out, const uint8_t* arg
 /* gradient of concat(upsample2x(a), b): da[N,H/2,W/2,C0] (=|+=) 2x2 sums of dcat[..., :C0]; db[N,H,W,C1] (=|+=) dcat[..., C0:]
  * (/root/reference/yolov3/yolov3_detector.py:115-116,140-141) */
 int yolo_upcat_split_bwd(const void* dcat, void* da, int acc_a, void* db, int acc_b, int N, int H, int W, int C0, int C1, void* stream);
+/* out[c] = sum over P partial rows (row stride in floats) of column c (bias gradient of the detection convs) */
+int yolo_reduce_partials(const float* partial, int P, int64_t row_stride, int C, float* out, void* stream);
+/* inference-mode BatchNorm (keras learning_phase False, /root/reference/run.py:21-24): scale/shift from the moving statistics */
+int yolo_bn_eval_scale_shift(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps,
+                             float* scale, float* shift, int C, void* stream);
 /* float32 NHWC images (C = 3, [0,1], BGR: /root/reference/dataset/file_util.py:58-59) -> bf16 NHWC8, channels 3..7 zero */
 int yolo_pack_input(const float* images, void* out, int64_t npix, int Cimg, void* stream);
 

@@ -1,0 +1,165 @@
+"""End-to-end parity of the native training step (ResNet18-YOLOv3, bf16 activations) against the CPU oracle.
+
+Two oracles are used: (a) the plain float32 restatement of the reference and (b) the same with the product's bf16 storage
+points emulated (weights, conv outputs and activations rounded to bf16), which isolates kernel errors from precision choice.
+Tolerances are written at each assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ANCHORS = [[(0.06618181818181816, 0.1025177510694752), (0.18544278606965178, 0.13160367921287464), (0.13, 0.32733333333333337)],
+           [(0.13, 0.32733333333333337), (0.303806787732042, 0.34370030784316496)],
+           [(0.303806787732042, 0.34370030784316496), (0.4667050847457627, 0.5281262429095761),
+            (0.7906945888923907, 0.7888860433597275)]]
+LOSS_W = [(5, 5, 0.05, 3, 1), (8, 8, 0.05, 2, 1), (10, 10, 0.05, 2, 1)]
+NAMES = ['yolov3_head_8', 'yolov3_head_16', 'yolov3_head_32']
+
+
+def make_batch(N, H, W, T, class_num, seed):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.rand(N, H, W, 3, generator=g).numpy()
+    labels = -np.ones((N, T, 5), dtype=np.float32)
+    for n in range(N):
+        k = int(torch.randint(1, T + 1, (1,), generator=g))
+        wh = torch.rand(k, 2, generator=g) * 0.5 + 0.05
+        xy = torch.rand(k, 2, generator=g) * (1 - wh) + wh / 2
+        cls = torch.randint(0, max(class_num, 1), (k, 1), generator=g).float()
+        labels[n, :k] = torch.cat([xy, wh, cls], 1).numpy()
+    return images, labels.reshape(N, T * 5)
+
+
+def build(backbone, H, W, N, class_num, rect):
+    from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
+    from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
+    from yolov3_tensorflow_amd.utils.radam import RAdam
+    L = 5 + class_num
+    chans = [len(a) * L for a in ANCHORS]
+    grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+    model = YOLOv3Detector(backbone).build((H, W, 3), chans, NAMES, batch_size=N)
+    loss = YOLOv3Loss(grids, class_num, ANCHORS, 0.5, LOSS_W, rectified_coord_num=rect, rectified_loss_weight=[1.0, 1.0, 1.0])
+    opt = RAdam(lr=1e-3)
+    model.compile(optimizer=opt, loss=loss.loss)
+    return model, loss, opt, grids
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
+
+
+@pytest.mark.parametrize('backbone', ['resnet-18', 'resnet-18-v2'])
+def test_forward_loss_grads_and_step(backbone):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from oracle.train import OracleTrainer
+    H = W = 96
+    N, T, Cn = 2, 4, 13
+    model, loss, opt, grids = build(backbone, H, W, N, Cn, rect=1464)
+    images, labels = make_batch(N, H, W, T, Cn, seed=3)
+    w0 = model.get_weights()
+    model.use_hip_graph = False
+
+    orc = {}
+    for tag, emu in (('f32', False), ('bf16', True)):
+        o = OracleTrainer(backbone, grids, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=1464, rectified_loss_weight=[1.0, 1.0, 1.0],
+                          emulate_bf16=emu)
+        o.ensure_params(images)
+        assert list(o.det.params.p.keys()) == list(w0.keys()) or set(o.det.params.p.keys()) == set(w0.keys())
+        o.set_weights(w0)
+        orc[tag] = o
+
+    # ---- forward + loss + backward on the GPU (no optimizer yet) ----
+    model.stage_batch(images, labels)
+    model.g.training = True
+    model._fwd_bwd()
+    torch.cuda.synchronize()
+    heads_gpu = [h.buf[..., :c].float().cpu() for h, c in zip(model.heads, model.head_channel_nums)]
+    loss_gpu = float(loss.total.item())
+    grad_flat = model.g.ps.grad.detach().cpu()
+
+    res = {}
+    for tag, o in orc.items():
+        for _, t in o.det.params.trainable():
+            t.grad = None
+        heads, yolo, l2 = o.forward_loss(images, labels)
+        yolo.backward()
+        res[tag] = (heads, float(yolo.item()), float(l2.item()))
+
+    # logits: bf16-emulating oracle within bf16 noise of a 20-layer stack (absolute 2e-2 on O(0.1..1) logits)
+    for hg, ho in zip(heads_gpu, res['bf16'][0]):
+        assert rel_l2(hg.numpy(), ho.detach().numpy()) < 3e-2
+    # loss: 1e-3 relative vs the bf16-emulating oracle (north_star's 1e-3), 2e-2 vs the float32 oracle (precision choice)
+    assert abs(loss_gpu - res['bf16'][1]) <= 1e-3 * abs(res['bf16'][1]), (loss_gpu, res['bf16'][1], res['f32'][1])
+    assert abs(loss_gpu - res['f32'][1]) <= 2e-2 * abs(res['f32'][1]), (loss_gpu, res['f32'][1])
+    # the loss kernel on the GPU's own logits must agree with the oracle loss on those logits to float32 accuracy
+    raw = [h.reshape(N, h.shape[1], h.shape[2], len(a), 5 + Cn) for h, a in zip(heads_gpu, ANCHORS)]
+    chk = OracleTrainer(backbone, grids, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=1464, rectified_loss_weight=[1.0, 1.0, 1.0])
+    lchk = float(chk.loss.loss_heads(torch.as_tensor(labels), raw).item())
+    assert abs(loss_gpu - lchk) <= 1e-4 * abs(lchk)
+
+    # gradients of every variable vs autograd of the bf16-emulating oracle: relative L2 error over the whole variable.
+    # bf16 gradient storage (2^-8 per element, random sign) through ~20 layers gives a few percent.
+    worst = 0.0
+    ps = model.g.ps
+    from yolov3_tensorflow_amd import engine
+    for p in ps.params.values():
+        t = grad_flat[p.offset:p.offset + p.numel]
+        if p.kind in ('conv_kernel', 'head_kernel'):
+            g_gpu = engine.Graph.kernel_from_dev(t, p).numpy()
+        else:
+            g_gpu = t[:p.tf_shape[0]].numpy()
+        g_ref = orc['bf16'].det.params.p[p.name].grad.detach().numpy().reshape(g_gpu.shape)
+        e = rel_l2(g_gpu, g_ref)
+        worst = max(worst, e)
+        assert e < 8e-2, (p.name, e)
+    print('worst relative gradient error', worst)
+
+    # ---- optimizer step: weights after one RAdam+L2 update vs the oracle step (same gradients path) ----
+    model._update()
+    torch.cuda.synchronize()
+    total_gpu = float(model.loss_value.item())
+    l2_gpu = float(model.l2_value.item())
+    assert abs(l2_gpu - res['f32'][2]) <= 1e-4 * abs(res['f32'][2])
+    assert abs(total_gpu - (loss_gpu + l2_gpu)) <= 1e-5 * abs(total_gpu)
+    o = orc['bf16']
+    o.loss.current_num = 0
+    o.opt = type(o.opt)(lr=1e-3, scalar_dtype=np.float64)
+    o.step(images, labels)
+    w1 = model.get_weights()
+    for n_, t in o.det.params.trainable():
+        d_gpu = w1[n_] - w0[n_]
+        d_ref = t.detach().numpy().reshape(w0[n_].shape) - w0[n_]
+        assert rel_l2(d_gpu, d_ref) < 8e-2, n_
+    # moving statistics were updated (momentum 0.9)
+    bn0 = model.g.bns[0].name
+    assert not np.allclose(w1[bn0 + '/moving_mean'], 0.0)
+    torch.testing.assert_close(torch.as_tensor(w1[bn0 + '/moving_mean']), o.det.params.p[bn0 + '/moving_mean'].detach(), rtol=2e-2, atol=1e-3)
+
+
+def test_loss_curve_graph_replay():
+    """6 steps with hipGraph replay vs the oracle (float32 and bf16-emulating); the first steps use the momentum-SGD branch,
+    step 6 switches to the adaptive branch (rho_t >= 5).  Tolerance: 2e-2 relative per step vs the float32 oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from oracle.train import OracleTrainer
+    H = W = 64
+    N, T, Cn = 2, 3, 4
+    model, loss, opt, grids = build('resnet-18', H, W, N, Cn, rect=6)
+    images, labels = make_batch(N, H, W, T, Cn, seed=9)
+    w0 = model.get_weights()
+    o = OracleTrainer('resnet-18', grids, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=6, rectified_loss_weight=[1.0, 1.0, 1.0])
+    o.ensure_params(images)
+    o.set_weights(w0)
+    curve_gpu, curve_ref = [], []
+    for step in range(6):
+        curve_gpu.append(model.train_on_batch(images, labels))
+        curve_ref.append(o.step(images, labels)[0])
+    print('gpu', curve_gpu)
+    print('ref', curve_ref)
+    assert opt.iterations == 6
+    assert int(loss.current_num.item()) == 8          # rectified counter: active while current_num <= 6 -> 4 steps of 2 images
+    for a, b in zip(curve_gpu, curve_ref):
+        assert abs(a - b) <= 2e-2 * abs(b), (curve_gpu, curve_ref)
+    assert curve_gpu[-1] < curve_gpu[0]

@@ -51,6 +51,8 @@ SIGNATURES = {
     'yolo_bn_pool_bwd_apply': (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     'yolo_upcat_split_bwd': (I, [P, P, I, P, I, I, I, I, I, I, P]),
     'yolo_pack_input': (I, [P, P, I64, I, P]),
+    'yolo_reduce_partials': (I, [P, I, I64, I, P, P]),
+    'yolo_bn_eval_scale_shift': (I, [P, P, P, P, F, P, P, I, P]),
     'yolo_loss_workspace_bytes': (I64, [LP, I]),
     'yolo_loss_fwd_bwd': (I, [LP, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'yolo_radam_schedule': (I, [P, P, F, F, F, F, P]),

@@ -1,0 +1,37 @@
+"""Pre-activation ResNet-18 of the reference (backbone/resnet18_v2.py:10-74)."""
+from yolov3_tensorflow_amd.backbone.basic_backbone import BasicBackbone
+
+
+class ResNet18_v2(BasicBackbone):
+
+    @classmethod
+    def _residual_v2_block(cls, input_x, filters, is_nin=True, **conv_params):
+        """reference :13-37 -- the NIN shortcut starts from the PRE-ACTIVATED tensor (:33-34), the identity one from the input (:36)"""
+        pre_activation = cls.bn_activation(input_x)
+        residual = cls.convolution(pre_activation, filters=filters, **conv_params)
+        conv_params.update(strides=(1, 1))
+        residual = cls.bn_activation(residual)
+        residual = cls.convolution(residual, filters=filters, **conv_params)
+        if is_nin:
+            return cls.element_wise_add(pre_activation, residual, is_nin=True)
+        return cls.element_wise_add(input_x, residual, is_nin=False)
+
+    @classmethod
+    def _residual_v2_module(cls, input_x, filters, **conv_params):
+        """reference :39-52"""
+        first_block = cls._residual_v2_block(input_x, filters, is_nin=True, **conv_params)
+        return cls._residual_v2_block(first_block, filters, is_nin=False)
+
+    @classmethod
+    def build(cls, input_x):
+        """reference :54-74 (stem conv has no BN; trailing BN+ReLU on the three outputs)"""
+        net = cls.convolution(input_x, filters=64, kernel_size=(3, 3), strides=(2, 2), padding='same')
+        net = cls.max_pooling(net)
+        net = cls._residual_v2_module(net, filters=64)
+        sub_stride_8_net = cls._residual_v2_module(net, filters=128, strides=(2, 2))
+        sub_stride_16_net = cls._residual_v2_module(sub_stride_8_net, filters=256, strides=(2, 2))
+        sub_stride_32_net = cls._residual_v2_module(sub_stride_16_net, filters=512, strides=(2, 2))
+        sub_stride_8_net = cls.bn_activation(sub_stride_8_net)
+        sub_stride_16_net = cls.bn_activation(sub_stride_16_net)
+        sub_stride_32_net = cls.bn_activation(sub_stride_32_net)
+        return sub_stride_8_net, sub_stride_16_net, sub_stride_32_net

@@ -382,6 +382,33 @@ __global__ __launch_bounds__(EW_THREADS) void pack_input_kernel(const float* __r
   }
 }
 
+// ---- out[c] = sum_p partial[p * rstride + c]  (column sums of partial rows; used for the detection-conv bias gradient) ----
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int P, size_t rstride, int C,
+                                                               float* __restrict__ out) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+  __shared__ double red[32][33];
+  double s = 0.0;
+  if (c < C)
+    for (int p = ry; p < P; p += 32) s += (double)part[(size_t)p * rstride + c];
+  red[ry][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    s = 0.0;
+    for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x & 31];
+    out[c] = (float)s;
+  }
+}
+
+// ---- inference-mode BatchNorm: scale/shift from the moving statistics (keras learning_phase False, run.py:21-24) ----
+__global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mm,
+                               const float* __restrict__ mv, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = (gamma ? gamma[c] : 1.f) * (1.f / sqrtf(mv[c] + eps));
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - mm[c] * sc;
+}
+
 inline int ew_grid(size_t items) {
   size_t b = (items + EW_THREADS - 1) / EW_THREADS;
   if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride beyond
@@ -540,6 +567,22 @@ extern "C" int yolo_pack_input(const float* images, void* out, int64_t npix, int
   YOLO_CHECK_ARG(images && out && npix > 0 && Cimg > 0 && Cimg <= 8, "bad argument");
   hipLaunchKernelGGL(pack_input_kernel, dim3(ew_grid((size_t)npix)), dim3(EW_THREADS), 0, (hipStream_t)stream, images, (bf16_t*)out,
                      (size_t)npix, Cimg);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_reduce_partials(const float* partial, int P, int64_t row_stride, int C, float* out, void* stream) {
+  YOLO_CHECK_ARG(partial && out && P > 0 && C > 0 && row_stride >= C, "bad argument");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride, C, out);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_eval_scale_shift(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps,
+                                        float* scale, float* shift, int C, void* stream) {
+  YOLO_CHECK_ARG(moving_mean && moving_var && scale && shift && C > 0, "bad argument");
+  hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, moving_mean, moving_var, eps,
+                     scale, shift, C);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

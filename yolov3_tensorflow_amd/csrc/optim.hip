@@ -15,21 +15,25 @@ namespace {
 __global__ void radam_schedule_kernel(float* __restrict__ f, long long* __restrict__ it, float beta1, float beta2, float decay,
                                       float warmup_coef) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float lr = f[0];
-  if (decay > 0.f) lr = lr * (1.f / (1.f + decay * (float)it[0]));  // radam.py:61-64 (uses the pre-increment counter)
-  it[0] += 1;                                                          // radam.py:66
-  const float t = (float)it[0];
-  const float b1p = powf(beta1, t), b2p = powf(beta2, t);              // radam.py:77-78
-  const float rho_inf = 2.f / (1.f - beta2) - 1.f;                     // radam.py:54
-  const float rho_t = rho_inf - 2.f * t * b2p / (1.f - b2p);           // radam.py:79
-  float lr_t;
-  if (rho_t >= 5.f)                                                    // radam.py:81-85
-    lr_t = sqrtf((rho_t - 4.f) * (rho_t - 2.f) * rho_inf / ((rho_inf - 4.f) * (rho_inf - 2.f) * rho_t)) * lr * (sqrtf(1.f - b2p) / (1.f - b1p));
+  // The reference evaluates this scalar chain in float32 (K.floatx()); there 1 - beta_2^t cancels catastrophically for small t
+  // (rho_t = rho_inf - 2t*b2^t/(1-b2^t) is a difference of two ~2e3 numbers), so float32 results differ by up to ~1 % between
+  // pow() implementations.  We evaluate in double -- the value every float32 implementation approximates -- and round once.
+  double lr = (double)f[0];
+  if (decay > 0.f) lr = lr * (1.0 / (1.0 + (double)decay * (double)it[0]));  // radam.py:61-64 (pre-increment counter)
+  it[0] += 1;                                                                  // radam.py:66
+  const double t = (double)it[0];
+  const double b1 = (double)beta1, b2 = (double)beta2;
+  const double b1p = pow(b1, t), b2p = pow(b2, t);                             // radam.py:77-78
+  const double rho_inf = 2.0 / (1.0 - b2) - 1.0;                               // radam.py:54
+  const double rho_t = rho_inf - 2.0 * t * b2p / (1.0 - b2p);                  // radam.py:79
+  double lr_t;
+  if (rho_t >= 5.0)                                                            // radam.py:81-85
+    lr_t = sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t)) * lr * (sqrt(1.0 - b2p) / (1.0 - b1p));
   else
-    lr_t = warmup_coef * lr / (1.f - b1p);
-  f[1] = lr_t;
-  f[2] = rho_t;
-  f[3] = rho_t >= 5.f ? 1.f : 0.f;
+    lr_t = (double)warmup_coef * lr / (1.0 - b1p);
+  f[1] = (float)lr_t;
+  f[2] = (float)rho_t;
+  f[3] = rho_t >= 5.0 ? 1.f : 0.f;
 }
 
 constexpr int OPT_THREADS = 256;

@@ -1,0 +1,548 @@
+"""Graph builder + executor of the MI355X-native training step.
+
+The reference builds a tf.keras graph from layer factories (backbone/basic_backbone.py) and lets TensorFlow run and
+differentiate it.  Here the same factory calls build a *lazy* graph of symbolic values; consecutive
+conv -> BN -> (+shortcut) -> ReLU / max-pool patterns are lowered onto the fused HIP kernels of libyolov3_amd.so, and the
+backward pass is a static tape built once.  All device memory (activations, gradients, statistics, the flat parameter /
+gradient / RAdam-state buffers) is allocated up front with torch (allocator only), so a whole step is a fixed launch
+sequence that can be captured into a hipGraph.
+
+Layout: activations NHWC bf16; conv kernels OHWI (bf16 compute copy + float32 master, both inside flat buffers whose
+slots are padded to 256 elements); detection-conv outputs padded to 64*2^k channels, the RGB stem padded 3 -> 8 channels.
+"""
+import collections
+import math
+import numpy as np
+import torch
+from . import ops
+
+L2_CONV_DECAY = 5e-4       # reference backbone/basic_backbone.py:11
+BN_L2_GAMMA_DECAY = 1e-5   # :12
+BN_MOMENTUM = 0.9          # :13
+BN_EPSILON = 1e-5          # :14
+SLOT = 256                 # flat-buffer slot granularity (elements)
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class Param(object):
+    """one variable of the model: a slot of the flat buffers + its Keras name / TF shape for checkpoints"""
+
+    def __init__(self, name, kind, tf_shape, dev_shape, l2):
+        self.name, self.kind, self.tf_shape, self.dev_shape, self.l2 = name, kind, tuple(tf_shape), tuple(dev_shape), l2
+        self.numel = int(np.prod(dev_shape))
+        self.offset = None
+        self.init = None          # float32 CPU tensor in device layout
+
+
+class ParamStore(object):
+    """flat float32 params / grads / m / v and the bf16 compute copy; Keras-style auto names"""
+
+    def __init__(self, seed=800):
+        self.params = collections.OrderedDict()
+        self.state = collections.OrderedDict()     # non-trainable (moving statistics): name -> (tf_shape, init tensor)
+        self.counters = collections.Counter()
+        self.gen = torch.Generator().manual_seed(seed)
+        self.total = 0
+        self.flat = None
+
+    def layer_name(self, base):
+        k = self.counters[base]
+        self.counters[base] += 1
+        return base if k == 0 else '%s_%d' % (base, k)
+
+    def add(self, p, init):
+        p.offset = self.total
+        p.init = init.reshape(-1).float()
+        self.total += _round_up(p.numel, SLOT)
+        self.params[p.name] = p
+        return p
+
+    def he_normal(self, shape, fan_in):
+        """keras 'he_normal': truncated normal (+-2 sigma), stddev = sqrt(2/fan_in)/.87962566103423978"""
+        std = math.sqrt(2.0 / fan_in) / .87962566103423978
+        t = torch.empty(shape, dtype=torch.float32)
+        torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=self.gen)
+        return t
+
+    def allocate(self, device):
+        n = max(self.total, SLOT)
+        self.n = n
+        host = torch.zeros(n)
+        l2 = torch.zeros(n // SLOT)
+        for p in self.params.values():
+            host[p.offset:p.offset + p.numel] = p.init
+            l2[p.offset // SLOT:(p.offset + _round_up(p.numel, SLOT)) // SLOT] = p.l2
+        self.flat = host.to(device)
+        self.grad = torch.zeros(n, device=device)
+        self.m = torch.zeros(n, device=device)
+        self.v = torch.zeros(n, device=device)
+        self.bf16 = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        self.l2_table = l2.to(device)
+        ops.cast_f32_to_bf16(self.flat, self.bf16, n)
+
+    def view(self, p, buf=None):
+        buf = self.flat if buf is None else buf
+        return buf[p.offset:p.offset + p.numel]
+
+
+class BNState(object):
+    def __init__(self, g, name, C):
+        self.name, self.C = name, C
+        ps = g.ps
+        self.gamma = ps.add(Param(name + '/gamma', 'bn_gamma', (C,), (C,), BN_L2_GAMMA_DECAY), torch.ones(C))
+        self.beta = ps.add(Param(name + '/beta', 'bn_beta', (C,), (C,), 0.0), torch.zeros(C))
+        ps.state[name + '/moving_mean'] = self
+        ps.state[name + '/moving_variance'] = self
+
+    def allocate(self, dev):
+        C = self.C
+        self.moving_mean = torch.zeros(C, device=dev)
+        self.moving_var = torch.ones(C, device=dev)
+        (self.scale, self.shift, self.mean, self.rstd, self.k1, self.k2) = [torch.zeros(C, device=dev) for _ in range(6)]
+
+
+class Val(object):
+    """symbolic value.  kind: input | act | conv | bn | sum | pool | up | cat"""
+
+    def __init__(self, g, kind, shape, **kw):
+        self.g, self.kind, self.shape = g, kind, tuple(shape)    # shape = (N, H, W, C)
+        self.__dict__.update(kw)
+        self.buf = None
+        self.grad = None
+        self.grad_init = False
+        self.needs_grad = True
+        self.cached = None
+
+    @property
+    def M(self):
+        return self.shape[0] * self.shape[1] * self.shape[2]
+
+
+class Graph(object):
+    def __init__(self, batch, device, seed=800):
+        self.N = batch
+        self.dev = device
+        self.ps = ParamStore(seed)
+        self.tape = []
+        self.vals = []
+        self.bns = []
+        self.fwd, self.bwd = [], []
+        self.training = True
+        self._alloc = []
+
+    # ------------------------------------------------------------------------------------------------ allocation helpers
+    def _buffer(self, shape, dtype=torch.bfloat16):
+        cell = {}
+        self._alloc.append((cell, tuple(shape), dtype))
+        return cell
+
+    # ------------------------------------------------------------------------------------------------ factories
+    def input(self, H, W, C=3):
+        v = Val(self, 'input', (self.N, H, W, C))
+        v.needs_grad = False
+        self.input_val = v
+        return v
+
+    def _as_conv_input(self, x):
+        """a conv reads an activation, the packed input image, or concat(upsample(act), act)"""
+        if x.kind in ('act', 'input'):
+            return x
+        if x.kind == 'cat' and x.a.kind == 'up' and x.a.src.kind == 'act' and x.b.kind == 'act':
+            return x
+        return self.materialize(x, relu=False)
+
+    def convolution(self, x, filters, kernel_size=(3, 3), strides=(1, 1), padding='same', use_bias=False, name=None,
+                    init='he_normal'):
+        x = self._as_conv_input(x)
+        k, s = int(kernel_size[0]), int(strides[0])
+        N, H, W, Cin = x.shape
+        name = name or self.ps.layer_name('conv2d')
+        cin_dev = 8 if x.kind == 'input' else Cin
+        cout_dev = ops.pad_channels(filters) if use_bias else filters
+        if init == 'he_normal':
+            w = self.ps.he_normal((k, k, Cin, filters), k * k * Cin)
+            kind, l2 = 'conv_kernel', L2_CONV_DECAY
+        else:                                     # RandomNormal(stddev=0.01), no regulariser (yolov3_detector.py:98-100)
+            w = torch.randn((k, k, Cin, filters), generator=self.ps.gen) * 0.01
+            kind, l2 = 'head_kernel', 0.0
+        wp = Param(name + '/kernel', kind, (k, k, Cin, filters), (cout_dev, k, k, cin_dev), l2)
+        self.ps.add(wp, self.kernel_to_dev(w, wp))
+        bp = None
+        if use_bias:
+            bp = self.ps.add(Param(name + '/bias', 'bias', (filters,), (cout_dev,), 0.0), torch.zeros(cout_dev))
+        C0 = x.a.src.shape[3] if x.kind == 'cat' else 0
+        p = ops.conv_problem(N, H, W, cin_dev, cout_dev, k, s, padding, C0=C0)
+        y = Val(self, 'conv', (N, p.Ho, p.Wo, cout_dev), x=x, wp=wp, bp=bp, p=p, f32=use_bias, filters=filters)
+        y.cell = self._buffer(y.shape, torch.float32 if use_bias else torch.bfloat16)
+        y.dy_cell = self._buffer(y.shape, torch.bfloat16)
+        y.stat_rows = ops.conv2d_stat_rows(p)
+        y.stat_cell = None if use_bias else self._buffer((2, y.stat_rows, cout_dev), torch.float32)
+        y.wants_stats = False
+        self.tape.append(ConvOp(self, y))
+        return y
+
+    @staticmethod
+    def kernel_to_dev(w_hwio, wp):
+        """TF HWIO -> device OHWI, zero-padded to the device shape"""
+        co, k, _, ci = wp.dev_shape
+        out = torch.zeros(wp.dev_shape)
+        w = w_hwio.permute(3, 0, 1, 2)
+        out[:w.shape[0], :, :, :w.shape[3]] = w
+        return out
+
+    @staticmethod
+    def kernel_from_dev(w_dev, wp):
+        k, _, ci, co = wp.tf_shape
+        return w_dev.reshape(wp.dev_shape)[:co, :, :, :ci].permute(1, 2, 3, 0).contiguous()
+
+    def batch_normalization(self, x):
+        if x.kind not in ('conv', 'act'):
+            x = self.materialize(x, relu=False)
+        C = x.shape[3]
+        bn = BNState(self, self.ps.layer_name('batch_normalization_v1'), C)
+        self.bns.append(bn)
+        if x.kind == 'conv':
+            x.wants_stats = True
+        return Val(self, 'bn', x.shape, src=x, bn=bn)
+
+    def activation(self, x):
+        return self.materialize(x, relu=True)
+
+    def add(self, identity, residual):
+        if identity.kind not in ('bn', 'conv', 'act'):
+            identity = self.materialize(identity, relu=False)
+        if residual.kind not in ('bn', 'conv', 'act'):
+            residual = self.materialize(residual, relu=False)
+        return Val(self, 'sum', residual.shape, a=identity, b=residual)
+
+    def max_pool(self, x):
+        N, H, W, C = x.shape
+        Ho, pt = ops.same_pad(H, 3, 2)
+        Wo, pl = ops.same_pad(W, 3, 2)
+        return Val(self, 'pool', (N, Ho, Wo, C), src=x, pt=pt, pl=pl)
+
+    def up_sample(self, x):
+        x = self.materialize(x, relu=False)
+        N, H, W, C = x.shape
+        return Val(self, 'up', (N, 2 * H, 2 * W, C), src=x)
+
+    def concat(self, a, b):
+        if b.kind != 'act':
+            b = self.materialize(b, relu=False)
+        return Val(self, 'cat', b.shape[:3] + (a.shape[3] + b.shape[3],), a=a, b=b)
+
+    # ------------------------------------------------------------------------------------------------ lowering
+    def materialize(self, v, relu):
+        if v.kind == 'act' and not relu:
+            return v
+        if v.cached is not None and v.cached[0] == relu:
+            return v.cached[1]
+        out = Val(self, 'act', v.shape)
+        out.cell = self._buffer(out.shape)
+        out.grad_cell = self._buffer(out.shape)
+        if v.kind in ('bn', 'conv', 'act'):
+            op = ApplyOp(self, out, relu, main=v)
+        elif v.kind == 'sum':
+            a, b = v.a, v.b
+            for t in (a, b):
+                if t.kind not in ('bn', 'conv', 'act'):
+                    raise NotImplementedError('sum operand of kind ' + t.kind)
+            main, other = (b, a) if b.kind in ('bn', 'conv') else (a, b)
+            op = ApplyOp(self, out, relu, main=main, other=other)
+        elif v.kind == 'pool':
+            op = PoolOp(self, out, relu, v)
+        else:
+            raise NotImplementedError('cannot materialise ' + v.kind)
+        self.tape.append(op)
+        v.cached = (relu, out)
+        return out
+
+    # ------------------------------------------------------------------------------------------------ finalisation
+    def finalize(self, heads, loss_cfg_kwargs=None):
+        """allocate every buffer, build the forward / backward launch lists"""
+        dev = self.dev
+        self.heads = heads
+        self.ps.allocate(dev)
+        for cell, shape, dtype in self._alloc:
+            cell['t'] = torch.zeros(shape, dtype=dtype, device=dev)
+        for bn in self.bns:
+            bn.allocate(dev)
+        N, H, W, C = self.input_val.shape
+        self.images = torch.zeros(N, H, W, C, device=dev)
+        self.input_val.buf = torch.zeros(N, H, W, 8, dtype=torch.bfloat16, device=dev)
+        # dgrad weight copies
+        n_dg = 0
+        for op in self.tape:
+            if isinstance(op, ConvOp) and op.needs_dgrad():
+                op.dg_off = n_dg
+                n_dg += _round_up(op.y.wp.numel, SLOT)
+        self.w_dgrad = torch.zeros(max(n_dg, SLOT), dtype=torch.bfloat16, device=dev)
+        for op in self.tape:
+            op.bind()
+        self.fwd = [lambda: ops.pack_input(self.images, self.input_val.buf, N * H * W, C)]
+        for op in self.tape:
+            self.fwd.append(op.forward)
+        self.bwd = []
+        for op in reversed(self.tape):
+            op.plan_backward()
+            self.bwd.append(op.backward)
+
+    def refresh_dgrad_weights(self):
+        for op in self.tape:
+            if isinstance(op, ConvOp) and op.needs_dgrad():
+                op.repack()
+
+    def run_forward(self):
+        for f in self.fwd:
+            f()
+
+    def run_backward(self):
+        for f in self.bwd:
+            f()
+
+
+# ==================================================================================================================== ops
+class ConvOp(object):
+    def __init__(self, g, y):
+        self.g, self.y = g, y
+
+    def needs_dgrad(self):
+        x = self.y.x
+        return x.kind != 'input'
+
+    def bind(self):
+        g, y = self.g, self.y
+        y.buf = y.cell['t']
+        y.dy = y.dy_cell['t']
+        ps = g.ps
+        self.w = ps.view(y.wp, ps.bf16)
+        self.dw = ps.view(y.wp, ps.grad)
+        self.bias = ps.view(y.bp) if y.bp is not None else None
+        self.dbias = ps.view(y.bp, ps.grad) if y.bp is not None else None
+        if y.stat_cell is not None and y.wants_stats:
+            st = y.stat_cell['t']
+            self.ssum, self.ssq = st[0], st[1]
+        else:
+            self.ssum = self.ssq = None
+        x = y.x
+        if x.kind == 'cat':
+            self.src0, self.src1 = x.a.src, x.b
+        else:
+            self.src0, self.src1 = None, x
+        if self.needs_dgrad():
+            self.w_dg = g.w_dgrad[self.dg_off:self.dg_off + y.wp.numel]
+        if y.bp is not None:
+            C = y.shape[3]
+            self.brow = ops.reduce_rows(y.M, C)
+            self.bpart = torch.zeros(self.brow, 2, C, device=g.dev)
+
+    def repack(self):
+        co, k, _, ci = self.y.wp.dev_shape
+        ops.repack_dgrad_weights(self.w, self.w_dg, co, k, k, ci)
+
+    def forward(self):
+        y = self.y
+        ops.conv2d_fwd(y.p, self.src1.buf, self.w, y.buf, src0=None if self.src0 is None else self.src0.buf, bias=self.bias,
+                       stat_sum=self.ssum, stat_sq=self.ssq)
+
+    def plan_backward(self):
+        y = self.y
+        self.acc = []
+        if not self.needs_dgrad():
+            return
+        x = y.x
+        if x.kind == 'cat':
+            self.dcat = torch.zeros(x.shape, dtype=torch.bfloat16, device=self.g.dev)
+            a, b = x.a.src, x.b
+            self.acc = [a.grad_init, b.grad_init]
+            a.grad_init = b.grad_init = True
+        else:
+            self.acc = [x.grad_init]
+            x.grad_init = True
+
+    def backward(self):
+        y = self.y
+        s0 = None if self.src0 is None else self.src0.buf
+        ops.conv2d_wgrad(y.p, self.src1.buf, y.dy, self.dw, src0=s0)
+        if self.dbias is not None:
+            C = y.shape[3]
+            ops.bn_stats(y.dy, y.M, C, self.bpart)
+            ops.reduce_partials(self.bpart, self.brow, 2 * C, C, self.dbias)
+        if not self.needs_dgrad():
+            return
+        x = y.x
+        if x.kind == 'cat':
+            import copy
+            pd = copy.copy(y.p)
+            pd.C0 = 0
+            ops.conv2d_dgrad(pd, y.dy, self.w_dg, self.dcat)
+            a, b = x.a.src, x.b
+            N, H, W, _ = x.shape
+            ops.upcat_split_bwd(self.dcat, a.grad, self.acc[0], b.grad, self.acc[1], N, H, W, a.shape[3], b.shape[3])
+        else:
+            ops.conv2d_dgrad(y.p, y.dy, self.w_dg, x.grad, accumulate=self.acc[0])
+
+
+def _branch(v):
+    """decompose an apply operand into (tensor value, bn state or None)"""
+    if v.kind == 'bn':
+        return v.src, v.bn
+    return v, None
+
+
+class ApplyOp(object):
+    """out = act(BN?(main) + T),  T = nothing | act | BN(conv)   (bn_act_fwd and its two backward passes)"""
+
+    def __init__(self, g, out, relu, main, other=None):
+        self.g, self.out, self.relu = g, out, relu
+        self.m_src, self.m_bn = _branch(main)
+        self.o_src, self.o_bn = (None, None) if other is None else _branch(other)
+        if self.o_src is not None and self.o_bn is None and self.o_src.kind == 'conv':
+            raise NotImplementedError('raw conv output as the secondary sum operand')
+
+    def bind(self):
+        g, out = self.g, self.out
+        out.buf = out.cell['t']
+        out.grad = out.grad_cell['t']
+        C = out.shape[3]
+        self.C, self.M = C, out.M
+        self.P = ops.reduce_rows(self.M, C)
+        self.partial = torch.zeros(self.P, 3, C, device=g.dev)
+        for src, bn in ((self.m_src, self.m_bn), (self.o_src, self.o_bn)):
+            if bn is not None and src.kind == 'act':        # BN over a materialised tensor: statistics by a separate pass
+                bn.stat_part = torch.zeros(self.P, 2, C, device=g.dev)
+        ps = g.ps
+        self.views = {}
+        for bn in (self.m_bn, self.o_bn):
+            if bn is not None:
+                self.views[bn] = (ps.view(bn.gamma), ps.view(bn.beta), ps.view(bn.gamma, ps.grad), ps.view(bn.beta, ps.grad))
+
+    def _finalize_bn(self, src, bn):
+        ga, be, _, _ = self.views[bn]
+        mm, mv = (bn.moving_mean, bn.moving_var)
+        if not self.g.training:        # keras learning_phase False (run.py:21-24): normalise with the moving statistics
+            ops.bn_eval_scale_shift(ga, be, mm, mv, BN_EPSILON, bn.scale, bn.shift, self.C)
+            return
+        if src.kind == 'conv':
+            st = src.stat_cell['t']
+            ops.bn_finalize(st[0], st[1], src.stat_rows, self.C, self.C, self.M, ga, be, BN_EPSILON, BN_MOMENTUM, mm, mv, bn.scale,
+                            bn.shift, bn.mean, bn.rstd)
+        else:
+            ops.bn_stats(src.buf, self.M, self.C, bn.stat_part)
+            ops.bn_finalize(bn.stat_part, bn.stat_part[0, 1], self.P, 2 * self.C, self.C, self.M, ga, be, BN_EPSILON, BN_MOMENTUM, mm,
+                            mv, bn.scale, bn.shift, bn.mean, bn.rstd)
+
+    def forward(self):
+        if self.m_bn is not None:
+            self._finalize_bn(self.m_src, self.m_bn)
+        if self.o_bn is not None:
+            self._finalize_bn(self.o_src, self.o_bn)
+        sc, sh = (self.m_bn.scale, self.m_bn.shift) if self.m_bn is not None else (None, None)
+        kw = {}
+        if self.o_src is not None:
+            kw['res'] = self.o_src.buf
+            if self.o_bn is not None:
+                kw['res_scale'], kw['res_shift'] = self.o_bn.scale, self.o_bn.shift
+        ops.bn_act_fwd(self.m_src.buf, sc, sh, self.out.buf, self.M, self.C, self.relu, **kw)
+
+    def plan_backward(self):
+        # main branch gradient destination
+        m = self.m_src
+        if m.kind == 'conv':
+            self.m_dst, self.m_acc = 'dy', False
+        else:
+            self.m_dst, self.m_acc = 'grad', m.grad_init
+            m.grad_init = True
+        o = self.o_src
+        self.o_acc = False
+        if o is not None and o.kind == 'act':
+            self.o_acc = o.grad_init
+            o.grad_init = True
+
+    def backward(self):
+        out, m, o = self.out, self.m_src, self.o_src
+        mb, ob = self.m_bn, self.o_bn
+        need_reduce = mb is not None or ob is not None
+        if need_reduce:
+            # the reduce kernel always needs a (y, mean, rstd) triple for quantity 1; use the main BN if present
+            y1, b1 = (m, mb) if mb is not None else (o, ob)
+            y2, b2 = (o, ob) if (mb is not None and ob is not None) else (None, None)
+            ops.bn_act_bwd_reduce(out.grad, out.buf, self.relu, y1.buf, b1.mean, b1.rstd, self.M, self.C, self.partial,
+                                  y2=None if y2 is None else y2.buf, mean2=None if b2 is None else b2.mean,
+                                  rstd2=None if b2 is None else b2.rstd)
+            _, _, dga, dbe = self.views[b1]
+            ops.bn_bwd_finalize(self.partial, self.P, self.C, 1, self.M, dga, dbe, b1.k1, b1.k2)
+            if b2 is not None:
+                _, _, dga2, dbe2 = self.views[b2]
+                ops.bn_bwd_finalize(self.partial, self.P, self.C, 2, self.M, dga2, dbe2, b2.k1, b2.k2)
+        kw = {}
+        m_dst = m.dy if self.m_dst == 'dy' else m.grad
+        if mb is not None:
+            kw.update(y=m.buf, a1=mb.scale_g(), mean=mb.mean, rstd=mb.rstd, k1=mb.k1, k2=mb.k2)
+        kw.update(dy=m_dst, acc_dy=self.m_acc)
+        if o is not None:
+            if ob is not None:
+                kw.update(y2=o.buf, a2=ob.scale_g(), mean2=ob.mean, rstd2=ob.rstd, k1b=ob.k1, k2b=ob.k2, dy2=o.dy)
+            else:
+                kw.update(dres=o.grad, acc_dres=self.o_acc)
+        ops.bn_act_bwd_apply(out.grad, out.buf, self.relu, self.M, self.C, **kw)
+
+
+def _scale_g(self):
+    """gamma * rstd == the forward 'scale' vector"""
+    return self.scale
+
+
+BNState.scale_g = _scale_g
+
+
+class PoolOp(object):
+    """out = act(maxpool3x3s2(BN?(conv)))   (stem: resnet18.py:59-61; v2: resnet18_v2.py:61-62)"""
+
+    def __init__(self, g, out, relu, v):
+        self.g, self.out, self.relu, self.v = g, out, relu, v
+        self.src, self.bn = _branch(v.src)
+        if self.src.kind != 'conv':
+            raise NotImplementedError('max-pool over a non-conv value')
+
+    def bind(self):
+        g, out = self.g, self.out
+        out.buf = out.cell['t']
+        out.grad = out.grad_cell['t']
+        self.argmax = torch.zeros(out.shape, dtype=torch.uint8, device=g.dev)
+        N, H, W, C = self.src.shape
+        self.geom = (N, H, W, C, out.shape[1], out.shape[2], self.v.pt, self.v.pl)
+        self.P = ops.reduce_rows(N * H * W, C)
+        self.partial = torch.zeros(self.P, 3, C, device=g.dev)
+        if self.bn is not None:
+            ps = g.ps
+            self.views = (ps.view(self.bn.gamma), ps.view(self.bn.beta), ps.view(self.bn.gamma, ps.grad), ps.view(self.bn.beta, ps.grad))
+
+    def forward(self):
+        src, bn = self.src, self.bn
+        N, H, W, C = src.shape
+        if bn is not None and not self.g.training:
+            ops.bn_eval_scale_shift(self.views[0], self.views[1], bn.moving_mean, bn.moving_var, BN_EPSILON, bn.scale, bn.shift, C)
+        elif bn is not None:
+            st = src.stat_cell['t']
+            ops.bn_finalize(st[0], st[1], src.stat_rows, C, C, N * H * W, self.views[0], self.views[1], BN_EPSILON, BN_MOMENTUM,
+                            bn.moving_mean, bn.moving_var, bn.scale, bn.shift, bn.mean, bn.rstd)
+        ops.bn_pool_fwd(src.buf, None if bn is None else bn.scale, None if bn is None else bn.shift, self.out.buf, self.argmax,
+                        *self.geom, self.relu)
+
+    def plan_backward(self):
+        pass
+
+    def backward(self):
+        src, bn, out = self.src, self.bn, self.out
+        N, H, W, C = src.shape
+        if bn is not None:
+            ops.bn_pool_bwd_reduce(out.grad, out.buf, self.argmax, self.relu, src.buf, bn.mean, bn.rstd, *self.geom, self.partial)
+            ops.bn_bwd_finalize(self.partial, self.P, C, 1, N * H * W, self.views[2], self.views[3], bn.k1, bn.k2)
+            ops.bn_pool_bwd_apply(out.grad, out.buf, self.argmax, self.relu, src.buf, bn.scale, bn.mean, bn.rstd, bn.k1, bn.k2, src.dy,
+                                  *self.geom)
+        else:
+            ops.bn_pool_bwd_apply(out.grad, out.buf, self.argmax, self.relu, None, None, None, None, None, None, src.dy, *self.geom)

@@ -1,0 +1,240 @@
+"""YOLOv3Model: what ``YOLOv3Detector.build`` returns in place of the reference's keras Model
+(yolov3/yolov3_detector.py:55-59) -- the static native graph plus the keras-like calls the trainer uses
+(compile / train_on_batch / predict / save_weights / load_weights).
+
+A training step (reference: one session.run of forward, YOLOv3Loss.loss, tf.gradients, RAdam.get_updates, trainer.py:84,113)
+is a fixed sequence of kernel launches on one HIP stream, captured once into a hipGraph and replayed:
+    pack input -> forward -> loss fwd+bwd -> backward -> [RCCL all-reduce of the flat gradient] -> RAdam+L2 -> weight repack
+"""
+import os
+import json
+import numpy as np
+import torch
+from . import engine, ops
+
+
+class YOLOv3Model(object):
+    def __init__(self, detector, input_image_size, head_channel_nums, head_names, batch_size=None, device=None, seed=800):
+        from . import configs
+        if not torch.cuda.is_available():
+            raise RuntimeError('the MI355X-native path needs a GPU (no CPU fallback)')
+        self.name = detector.backbone_name
+        self.batch_size = int(batch_size if batch_size is not None else configs.FLAGS.batch_size)
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self.input_image_size = list(input_image_size)
+        self.head_channel_nums = list(head_channel_nums)
+        self.head_names = list(head_names)
+        H, W, C = self.input_image_size
+        if H % 32 or W % 32:
+            raise ValueError('input height/width must be multiples of 32')
+        with torch.cuda.device(self.device):
+            g = engine.Graph(self.batch_size, self.device, seed)
+            x = g.input(H, W, C)
+            heads = detector._detection_head(detector.backbone.build(x), self.head_channel_nums, self.head_names)
+            g.finalize(heads)
+            g.refresh_dgrad_weights()
+        self.g = g
+        self.heads = heads                       # engine.Val (kind 'conv', float32, channel-padded), order /8, /16, /32
+        self.ldc = [h.shape[3] for h in heads]
+        self.loss_obj = None
+        self.optimizer = None
+        self._graphs = None
+        self.world_size, self.rank = 1, 0
+        self.process_group = None
+        self.use_hip_graph = True
+        self.loss_value = torch.zeros(1, device=self.device)
+        self.l2_value = torch.zeros(1, device=self.device)
+
+    # ---------------------------------------------------------------------------------------------- keras-like surface
+    def summary(self):
+        ps = self.g.ps
+        n = sum(int(np.prod(p.tf_shape)) for p in ps.params.values())
+        print('%s: %d trainable parameters in %d variables, %d kernels launches per forward' % (self.name, n, len(ps.params), len(self.g.fwd)))
+
+    def count_params(self):
+        return sum(int(np.prod(p.tf_shape)) for p in self.g.ps.params.values())
+
+    def compile(self, optimizer, loss):
+        """optimizer: utils.radam.RAdam; loss: the bound ``YOLOv3Loss.loss`` (reference trainer.py:84) or the object"""
+        self.optimizer = optimizer
+        self.loss_obj = getattr(loss, '__self__', loss)
+        self.loss_obj.bind(self)
+        optimizer.bind(self)
+        self._graphs = None
+
+    def set_distributed(self, world_size, rank, process_group=None):
+        self.world_size, self.rank, self.process_group = world_size, rank, process_group
+        self._graphs = None
+
+    # ---------------------------------------------------------------------------------------------- step
+    def _fwd_bwd(self):
+        g = self.g
+        g.run_forward()
+        self.loss_obj.launch(self)
+        g.run_backward()
+
+    def _update(self):
+        g = self.g
+        self.optimizer.launch(self)
+        g.refresh_dgrad_weights()
+
+    def _capture(self):
+        if not self.use_hip_graph:
+            self._graphs = (None, None)
+            return
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(ga, stream=s):
+                self._fwd_bwd()
+            with torch.cuda.graph(gb, stream=s):
+                self._update()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        self._graphs = (ga, gb)
+
+    def stage_batch(self, images, labels):
+        """host -> device copy of one batch into the static input buffers (outside the timed region of bench.py)"""
+        g = self.g
+        img = torch.as_tensor(np.asarray(images, dtype=np.float32) if not torch.is_tensor(images) else images)
+        lab = torch.as_tensor(np.asarray(labels, dtype=np.float32) if not torch.is_tensor(labels) else labels)
+        if tuple(img.shape) != tuple(g.images.shape):
+            raise ValueError('images must have shape %s (static graph), got %s' % (tuple(g.images.shape), tuple(img.shape)))
+        g.images.copy_(img.to(torch.float32), non_blocking=True)
+        self.loss_obj.stage_labels(lab)
+
+    def run_step(self):
+        """one training step on the staged batch; returns nothing (loss stays on the device in self.loss_value)"""
+        if self.loss_obj is None or self.optimizer is None:
+            raise RuntimeError('compile(optimizer, loss) first')
+        with torch.cuda.device(self.device):
+            if self._graphs is None:
+                self.g.training = True
+                self._capture()
+            ga, gb = self._graphs
+            if ga is None:
+                self._fwd_bwd()
+            else:
+                ga.replay()
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.all_reduce(self.g.ps.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+            if gb is None:
+                self._update()
+            else:
+                gb.replay()
+
+    def train_on_batch(self, images, labels):
+        self.stage_batch(images, labels)
+        self.run_step()
+        return float(self.loss_value.item())
+
+    def forward_only(self, images, training=False):
+        """run the forward kernels (no capture); returns the three head tensors (device, float32, padded channels)"""
+        g = self.g
+        with torch.cuda.device(self.device):
+            g.images.copy_(torch.as_tensor(np.asarray(images, dtype=np.float32) if not torch.is_tensor(images) else images))
+            prev = g.training
+            g.training = training
+            try:
+                g.run_forward()
+            finally:
+                g.training = prev
+        return [h.buf for h in self.heads]
+
+    def predict(self, test_images):
+        """reference trainer.py:117-124 / keras Model.predict: float32 (n,H,W,3) in [0,1] BGR -> float32 ndarray
+        (n, H/32, W/32, C8*16 + C16*4 + C32) in the reference's merged layout (yolov3_detector.py:80-85)"""
+        x = np.asarray(test_images, dtype=np.float32)
+        n, N = x.shape[0], self.batch_size
+        outs = []
+        for i in range(0, n, N):
+            chunk = x[i:i + N]
+            if chunk.shape[0] < N:
+                chunk = np.concatenate([chunk, np.zeros((N - chunk.shape[0],) + chunk.shape[1:], np.float32)], axis=0)
+            heads = self.forward_only(chunk, training=False)
+            outs.append(self.merge_heads(heads)[:min(N, n - i)])
+        return np.concatenate(outs, axis=0)
+
+    def merge_heads(self, heads):
+        H32, W32 = self.input_image_size[0] // 32, self.input_image_size[1] // 32
+        parts = []
+        for t, c in zip(heads, self.head_channel_nums):
+            parts.append(t[..., :c].reshape(t.shape[0], H32, W32, -1))
+        return torch.cat(parts, dim=-1).float().cpu().numpy()
+
+    # ---------------------------------------------------------------------------------------------- weights by Keras name
+    def get_weights(self):
+        """{keras variable name: float32 ndarray in TF layout (HWIO kernels)}, trainable + moving statistics"""
+        ps = self.g.ps
+        flat = ps.flat.detach().cpu()
+        out = {}
+        for p in ps.params.values():
+            t = flat[p.offset:p.offset + p.numel]
+            if p.kind in ('conv_kernel', 'head_kernel'):
+                out[p.name] = engine.Graph.kernel_from_dev(t, p).numpy()
+            elif p.kind == 'dw_kernel':
+                out[p.name] = engine.Graph.dw_from_dev(t, p).numpy()
+            else:
+                out[p.name] = t[:p.tf_shape[0]].clone().numpy()
+        for bn in self.g.bns:
+            out[bn.name + '/moving_mean'] = bn.moving_mean.cpu().numpy()
+            out[bn.name + '/moving_variance'] = bn.moving_var.cpu().numpy()
+        return out
+
+    def set_weights(self, weights):
+        ps = self.g.ps
+        flat = ps.flat.detach().cpu()
+        for p in ps.params.values():
+            if p.name not in weights:
+                raise KeyError('missing variable ' + p.name)
+            w = torch.as_tensor(np.asarray(weights[p.name], dtype=np.float32))
+            if tuple(w.shape) != p.tf_shape:
+                raise ValueError('%s: expected shape %s, got %s' % (p.name, p.tf_shape, tuple(w.shape)))
+            if p.kind in ('conv_kernel', 'head_kernel'):
+                t = engine.Graph.kernel_to_dev(w, p)
+            elif p.kind == 'dw_kernel':
+                t = engine.Graph.dw_to_dev(w, p)
+            else:
+                t = torch.zeros(p.dev_shape)
+                t[:w.shape[0]] = w
+            flat[p.offset:p.offset + p.numel] = t.reshape(-1)
+        with torch.cuda.device(self.device):
+            ps.flat.copy_(flat)
+            ops.cast_f32_to_bf16(ps.flat, ps.bf16, ps.n)
+            for bn in self.g.bns:
+                if bn.name + '/moving_mean' in weights:
+                    bn.moving_mean.copy_(torch.as_tensor(np.asarray(weights[bn.name + '/moving_mean'], dtype=np.float32)))
+                    bn.moving_var.copy_(torch.as_tensor(np.asarray(weights[bn.name + '/moving_variance'], dtype=np.float32)))
+            self.g.refresh_dgrad_weights()
+            torch.cuda.synchronize(self.device)
+
+    def save_weights(self, path):
+        """weights-only checkpoint under the reference's file stem (trainer.py:90-91).  The TF SSTable byte format cannot be
+        produced without TensorFlow: variables are stored by Keras name in ``<path>.npz`` and a TF-style
+        ``checkpoint`` pointer file names the latest stem."""
+        d = os.path.dirname(path)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        np.savez(path + '.npz', **self.get_weights())
+        with open(os.path.join(d, 'checkpoint'), 'w') as f:
+            f.write('model_checkpoint_path: %s\n' % json.dumps(os.path.basename(path)))
+
+    def load_weights(self, path):
+        p = path if path.endswith('.npz') else path + '.npz'
+        with np.load(p, allow_pickle=False) as z:
+            self.set_weights({k: z[k] for k in z.files})
+
+
+def latest_checkpoint(directory):
+    """tf.train.latest_checkpoint semantics (reference trainer.py:60): read the ``checkpoint`` pointer file"""
+    ptr = os.path.join(directory, 'checkpoint')
+    if not os.path.exists(ptr):
+        return None
+    with open(ptr) as f:
+        line = f.readline().strip()
+    if not line.startswith('model_checkpoint_path:'):
+        return None
+    stem = json.loads(line.split(':', 1)[1].strip())
+    full = os.path.join(directory, stem)
+    return full if os.path.exists(full + '.npz') else None

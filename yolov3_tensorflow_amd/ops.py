@@ -123,6 +123,15 @@ def upcat_split_bwd(dcat, da, acc_a, db, acc_b, N, H, W, C0, C1):
           'yolo_upcat_split_bwd')
 
 
+def reduce_partials(partial, P, row_stride, Cc, out):
+    check(_lib.load().yolo_reduce_partials(_p(partial), P, row_stride, Cc, _p(out), _stream()), 'yolo_reduce_partials')
+
+
+def bn_eval_scale_shift(gamma, beta, mm, mv, eps, scale, shift, Cc):
+    check(_lib.load().yolo_bn_eval_scale_shift(_p(gamma), _p(beta), _p(mm), _p(mv), eps, _p(scale), _p(shift), Cc, _stream()),
+          'yolo_bn_eval_scale_shift')
+
+
 def pack_input(images, out, npix, cimg):
     check(_lib.load().yolo_pack_input(_p(images), _p(out), npix, cimg, _stream()), 'yolo_pack_input')
 

@@ -1,0 +1,128 @@
+"""YOLOv3Trainer with the reference's constructor and methods (yolov3/trainer.py:19-185): build model, (data-parallel wrap),
+load the latest checkpoint, choose the optimizer, build the loss, compile, run the epoch loop with the reference's callbacks
+(checkpoint every ``ckpt_period`` epochs, early stopping on the epoch loss, per-epoch learning-rate schedule, detailed loss log).
+"""
+import logging
+import os
+import time
+import numpy as np
+
+from yolov3_tensorflow_amd.configs import FLAGS
+from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
+from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
+from yolov3_tensorflow_amd import model as model_lib
+
+
+class YOLOv3Trainer(object):
+    GPU_MODE = 'gpu'
+    CPU_MODE = 'cpu'
+
+    def __init__(self):
+        """reference :30-97"""
+        self.backbone = FLAGS.model_backbone
+        self.input_image_size = FLAGS.input_image_size
+        self.head_channel_nums = FLAGS.head_channel_nums
+        if FLAGS.gpu_mode == YOLOv3Trainer.CPU_MODE:
+            raise RuntimeError("gpu_mode 'cpu' is not available: this is the MI355X-native path (no CPU fallback)")
+        self.model = YOLOv3Detector(self.backbone).build(self.input_image_size, self.head_channel_nums, FLAGS.head_names)
+        # reference :40-43 wraps the model with keras multi_gpu_model; here data parallelism is one process per GPU
+        # (torch.distributed / RCCL): see yolov3_tensorflow_amd.parallel.setup_data_parallel, called when WORLD_SIZE > 1.
+        from yolov3_tensorflow_amd import parallel
+        parallel.setup_data_parallel(self.model)
+        self.model.summary()
+        self.history = None
+
+        # load pre-trained weights if any (reference :47-67)
+        self.checkpoint_path = FLAGS.checkpoint_path
+        if self.checkpoint_path is None:
+            self.checkpoint_path = 'models/'
+        if os.path.isfile(self.checkpoint_path) or os.path.isfile(self.checkpoint_path + '.npz'):
+            self.model.load_weights(self.checkpoint_path)
+            logging.info('weights loaded')
+            self.checkpoint_path = os.path.dirname(self.checkpoint_path)
+        if os.path.isdir(self.checkpoint_path):
+            latest = model_lib.latest_checkpoint(self.checkpoint_path)
+            if latest is not None:
+                self.model.load_weights(latest)
+                logging.info('weights loaded: %s', latest)
+        else:
+            self.checkpoint_path = os.path.dirname(self.checkpoint_path)
+        self.checkpoint_path = os.path.join(self.checkpoint_path, FLAGS.checkpoint_name)
+
+        # optimizer (reference :69-75); RAdam(lr=1e-3) ignores FLAGS.init_lr exactly like the reference
+        if FLAGS.optimizer == 'radam':
+            from yolov3_tensorflow_amd.utils.radam import RAdam
+            optimizer = RAdam(lr=1e-3)
+        else:
+            raise NotImplementedError("optimizer '%s': only 'radam' is on the MI355X hot path (SURVEY.md section 8a O1)" % FLAGS.optimizer)
+        self.loss_object = YOLOv3Loss(FLAGS.head_grid_sizes, FLAGS.class_num, FLAGS.anchor_boxes, FLAGS.iou_thresh,
+                                      FLAGS.loss_weights, rectified_coord_num=FLAGS.rectified_coord_num,
+                                      rectified_loss_weight=FLAGS.rectified_loss_weight, is_focal_loss=FLAGS.is_focal_loss,
+                                      focal_alpha=FLAGS.focal_alpha, focal_gamma=FLAGS.focal_gamma,
+                                      is_tiou_recall=FLAGS.is_tiou_recall)
+        self.loss_function = self.loss_object.loss
+        self.optimizer = optimizer
+        self.model.compile(optimizer=optimizer, loss=self.loss_function)
+        self.epoch = FLAGS.epoch
+        self.ckpt_period = FLAGS.ckpt_period
+        self.stop_patience, self.stop_min_delta = FLAGS.stop_patience, FLAGS.stop_min_delta
+        self.lr_func = FLAGS.lr_func
+
+    def train(self, train_set, val_set, train_steps=FLAGS.steps_per_epoch, val_steps=FLAGS.validation_steps):
+        """reference :99-115.  ``train_set`` yields (images float32 (N,H,W,3) in [0,1] BGR, labels float32 (N, T*5) padded -1)."""
+        it = iter(train_set)
+        best, wait = np.inf, 0
+        history = {'loss': [], 'lr': []}
+        is_main = self.model.rank == 0
+        for epoch in range(self.epoch):
+            lr = float(self.lr_func(epoch))                                 # LearningRateScheduler (reference :94)
+            self.optimizer.lr = lr
+            t0 = time.time()
+            losses = []
+            for _ in range(train_steps):
+                images, labels = next(it)
+                losses.append(self.model.train_on_batch(images, labels))
+            epoch_loss = float(np.mean(losses))                              # keras reports the running mean over the epoch
+            history['loss'].append(epoch_loss)
+            history['lr'].append(lr)
+            if is_main:
+                self._log_detail(epoch, lr, epoch_loss, time.time() - t0)     # DetailLossLogger (reference :95)
+                if (epoch + 1) % self.ckpt_period == 0:                      # ModelCheckpoint(period) (reference :90-91)
+                    path = self.checkpoint_path.format(epoch=epoch + 1, loss=epoch_loss)
+                    self.model.save_weights(path)
+                    logging.info('saved %s', path)
+            if best - epoch_loss > self.stop_min_delta:                      # EarlyStopping(monitor='loss') (reference :92-93)
+                best, wait = epoch_loss, 0
+            else:
+                wait += 1
+                if wait >= self.stop_patience:
+                    logging.info('early stopping at epoch %d', epoch + 1)
+                    break
+        self.history = history
+        logging.info('training finished')
+
+    def _log_detail(self, epoch, lr, loss, seconds):
+        lo = self.loss_object
+        logging.info('epoch %d: lr %.3g loss %.5f (%.2fs) l2 %.5f | rect %s xy %s wh %s noobj %s obj %s cls %s', epoch + 1, lr, loss, seconds,
+                     float(self.model.l2_value.item()), lo.rectified_coord_loss, lo.coord_loss_xy, lo.coord_loss_wh, lo.noobj_iou_loss,
+                     lo.obj_iou_loss, lo.class_loss)
+
+    def predict(self, test_images):
+        """reference :117-124"""
+        return self.model.predict(test_images)
+
+    def convert_multi2single(self):
+        """reference :126-138: every rank holds the full weights, so the latest checkpoint is already a single-GPU one;
+        kept for interface parity -- writes the ``single_`` copy the reference's test flow expects."""
+        dir_name = self.checkpoint_path if os.path.isdir(self.checkpoint_path) else os.path.dirname(self.checkpoint_path)
+        latest = model_lib.latest_checkpoint(dir_name)
+        if latest is None:
+            raise RuntimeError('no checkpoint to convert')
+        self.model.load_weights(latest)
+        self.model.save_weights(os.path.join(dir_name, 'single_' + os.path.basename(latest)))
+
+    def save_mobile(self):
+        raise NotImplementedError('frozen .pb export is TensorFlow-specific (out of scope, SURVEY.md section 2)')
+
+    def save_serving(self):
+        raise NotImplementedError('TF-Serving SavedModel export is TensorFlow-specific (out of scope, SURVEY.md section 2)')
