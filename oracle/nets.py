@@ -78,7 +78,10 @@ class Params(object):
 class Graph(object):
     """Functional executor.  ``params`` is created lazily on the first pass (build) and reused afterwards."""
 
-    def __init__(self, params=None, training=True, round_fn=None, dtype=torch.float32):
+    def __init__(self, params=None, training=True, round_fn=None, dtype=torch.float32, inject=None):
+        # inject: optional iterator of tensors; at every ACTIVATION storage point the computed value is replaced by the next
+        # injected tensor with a straight-through gradient, so autograd differentiates at exactly that forward state
+        self.inject = inject
         self.params = params if params is not None else Params(dtype=dtype)
         self.building = params is None
         self.training = training
@@ -97,7 +100,12 @@ class Graph(object):
         self.replay[base] += 1
         return base if k == 0 else '%s_%d' % (base, k)
 
-    def _r(self, x):
+    def _r(self, x, kind='act'):
+        if kind == 'act' and self.inject is not None:
+            g = next(self.inject).to(x.dtype)
+            if tuple(g.shape) != tuple(x.shape):
+                raise ValueError('injected tensor shape %s != %s' % (tuple(g.shape), tuple(x.shape)))
+            return x + (g - x).detach()
         return x if self.round_fn is None else _RoundSTE.apply(x, self.round_fn)
 
     # ---------------------------------------------------------------- basic_backbone.py:20-43
@@ -118,7 +126,7 @@ class Graph(object):
                 self.params.add(name + '/bias', torch.zeros(filters), 'bias')
         w = self.params.p[name + '/kernel']
         b = self.params.p[name + '/bias'] if use_bias else None
-        wq = self._r(w)
+        wq = self._r(w, kind='w')
         xin = x.permute(0, 3, 1, 2)
         H, W = x.shape[1], x.shape[2]
         if padding == 'same':
@@ -135,7 +143,7 @@ class Graph(object):
         if self.building:
             # keras he_normal fan_in for a (kh, kw, C, 1) depthwise kernel = kh*kw*C
             self.params.add(name + '/depthwise_kernel', self.params.he_normal((kh, kw, c, 1), kh * kw * c), 'conv_kernel')
-        w = self._r(self.params.p[name + '/depthwise_kernel'])
+        w = self._r(self.params.p[name + '/depthwise_kernel'], kind='w')
         xin = F.pad(x.permute(0, 3, 1, 2), (kw // 2, kw // 2, kh // 2, kh // 2))
         y = F.conv2d(xin, w.permute(2, 3, 0, 1), None, groups=c)
         return y.permute(0, 2, 3, 1)
@@ -198,15 +206,31 @@ class Graph(object):
 
 
 class _RoundSTE(torch.autograd.Function):
-    """value rounding with a straight-through gradient (emulates a bf16 storage point)."""
+    """value rounding with a straight-through gradient (emulates a bf16 storage point).  With ROUND_GRADS the incoming
+    gradient is rounded too: the product stores the gradient of every bf16 tensor in bf16 as well."""
+    ROUND_GRADS = False
 
     @staticmethod
     def forward(ctx, x, fn):
+        ctx.fn = fn
         return fn(x)
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        return (ctx.fn(g) if _RoundSTE.ROUND_GRADS else g), None
+
+
+class _GradRound(torch.autograd.Function):
+    """identity whose gradient is rounded (the d(logits) handed to the detection convs' backward are bf16)"""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.fn(g), None
 
 
 # ======================================================================== backbones
@@ -245,7 +269,7 @@ def resnet18_v2(g, x):
         return block(block(x, filters, True, strides), filters, False)
 
     net = g._r(g.convolution(x, 64, kernel_size=(3, 3), strides=(2, 2)))  # :61 (no BN)
-    net = g.max_pool(net)                                                # :62
+    net = g._r(g.max_pool(net))                                          # :62 (a stored tensor in the product; rounding is exact here)
     net = module(net, 64)
     c3 = module(net, 128, (2, 2))
     c4 = module(c3, 256, (2, 2))
@@ -321,18 +345,22 @@ class DetectorOracle(object):
         self.seed = seed
         self.dtype = dtype
 
-    def forward(self, images, training=True, round_fn=None):
+    def forward(self, images, training=True, round_fn=None, inject=None):
         """images (N,H,W,3) in [0,1] BGR -> (h8, h16, h32) raw logits NHWC; keeps the Graph in self.g"""
         if self.params is None:
             g = Graph(None, training, round_fn, self.dtype)
             g.params.gen.manual_seed(self.seed)
         else:
-            g = Graph(self.params, training, round_fn, self.dtype)
+            g = Graph(self.params, training, round_fn, self.dtype, inject=inject)
         g.begin()
         x = images.to(self.dtype)
-        if round_fn is not None:
+        if g.inject is not None:
+            x = next(g.inject).to(self.dtype)          # the packed (bf16) input image
+        elif round_fn is not None:
             x = round_fn(x)
         heads = detection_heads(g, self.backbone(g, x), self.head_channel_nums, self.head_names)
+        if round_fn is not None and _RoundSTE.ROUND_GRADS:
+            heads = tuple(_GradRound.apply(h, round_fn) for h in heads)
         self.params = g.params
         self.g = g
         return heads

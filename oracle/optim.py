@@ -42,9 +42,12 @@ class RAdamOracle(object):
             lr = lr * (f(1.) / (f(1.) + f(self.decay) * f(self.iterations)))           # radam.py:61-64
         self.iterations += 1                                                          # radam.py:66
         t = f(self.iterations)
-        b1p = np.power(f(self.beta_1), t)                                             # radam.py:77
-        b2p = np.power(f(self.beta_2), t)                                             # radam.py:78
-        rho_inf = f(self.rho_inf)
+        # beta_1 / beta_2 are float32 K.variables in the reference (radam.py:44-45), so their float32 values are what enters
+        # the chain, and rho_inf (radam.py:54) is computed from that float32 beta_2
+        beta_1, beta_2 = f(np.float32(self.beta_1)), f(np.float32(self.beta_2))
+        b1p = np.power(beta_1, t)                                                     # radam.py:77
+        b2p = np.power(beta_2, t)                                                     # radam.py:78
+        rho_inf = f(2.) / (f(1.) - beta_2) - f(1.)                                    # radam.py:54
         rho_t = rho_inf - f(2.0) * t * b2p / (f(1.0) - b2p)                           # radam.py:79
         if rho_t >= 5.0:                                                              # radam.py:81-85
             lr_t = np.sqrt((rho_t - f(4.)) * (rho_t - f(2.)) * rho_inf /

@@ -15,13 +15,14 @@ from oracle.optim import RAdamOracle
 class OracleTrainer(object):
     def __init__(self, backbone, head_grid_sizes, class_num, anchor_boxes, iou_thresh, loss_weights, rectified_coord_num=0,
                  rectified_loss_weight=None, is_focal_loss=False, focal_alpha=0.25, focal_gamma=2.0, is_tiou_recall=False,
-                 lr=1e-3, emulate_bf16=False, seed=800, scalar_dtype=np.float64):
+                 lr=1e-3, emulate_bf16=False, seed=800, scalar_dtype=np.float64, emulate_bf16_grads=False):
         L = 5 + class_num
         self.det = DetectorOracle(backbone, [len(a) * L for a in anchor_boxes], seed=seed)
         self.loss = YOLOv3LossOracle(head_grid_sizes, class_num, anchor_boxes, iou_thresh, loss_weights, rectified_coord_num,
                                      rectified_loss_weight, is_focal_loss, focal_alpha, focal_gamma, is_tiou_recall)
         self.opt = RAdamOracle(lr=lr, scalar_dtype=scalar_dtype)
         self.round_fn = bf16_round if emulate_bf16 else None
+        self.round_grads = bool(emulate_bf16_grads and emulate_bf16)
         self.box_num = [len(a) for a in anchor_boxes]
         self.L = L
 
@@ -36,8 +37,11 @@ class OracleTrainer(object):
             for n, t in self.det.params.p.items():
                 t.copy_(torch.as_tensor(np.asarray(weights[n], dtype=np.float32)).reshape(t.shape))
 
-    def forward_loss(self, images, labels):
-        heads = self.det.forward(torch.as_tensor(images), training=True, round_fn=self.round_fn)
+    def forward_loss(self, images, labels, inject=None):
+        from oracle import nets
+        nets._RoundSTE.ROUND_GRADS = self.round_grads
+        heads = self.det.forward(torch.as_tensor(images), training=True, round_fn=self.round_fn,
+                                 inject=None if inject is None else iter(inject))
         raw = [h.reshape(h.shape[0], h.shape[1], h.shape[2], b, self.L) for h, b in zip(heads, self.box_num)]
         yolo = self.loss.loss_heads(torch.as_tensor(labels), raw)
         l2 = self.det.l2_regulariser()

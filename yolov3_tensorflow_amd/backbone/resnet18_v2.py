@@ -13,8 +13,10 @@ class ResNet18_v2(BasicBackbone):
         residual = cls.bn_activation(residual)
         residual = cls.convolution(residual, filters=filters, **conv_params)
         if is_nin:
-            return cls.element_wise_add(pre_activation, residual, is_nin=True)
-        return cls.element_wise_add(input_x, residual, is_nin=False)
+            identity = cls.element_wise_add(pre_activation, residual, is_nin=True)
+        else:
+            identity = cls.element_wise_add(input_x, residual, is_nin=False)
+        return identity.g.materialize(identity, relu=False)     # the block output is a stored tensor (no activation follows)
 
     @classmethod
     def _residual_v2_module(cls, input_x, filters, **conv_params):
