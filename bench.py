@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py -- training throughput of the MI355X-native YOLOv3 hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one full training step (pack input, forward, YOLOv3 loss fwd+bwd, backward, [RCCL gradient all-reduce], RAdam+L2
+update, weight repack) on one synthetic COCO-shaped batch already resident in HBM.  Workload = BASELINE.json configs[1]:
+ResNet18-YOLOv3 416x416 bf16, 80 classes, batch 32 per GPU (weak scaling: global batch = 32 * N = configs[2] at N = 8).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# COCO-9 anchors normalised by 416 (w, h), 3/3/3 per head
+COCO_ANCHORS = [[(10 / 416., 13 / 416.), (16 / 416., 30 / 416.), (33 / 416., 23 / 416.)],
+                [(30 / 416., 61 / 416.), (62 / 416., 45 / 416.), (59 / 416., 119 / 416.)],
+                [(116 / 416., 90 / 416.), (156 / 416., 198 / 416.), (373 / 416., 326 / 416.)]]
+LOSS_WEIGHTS = [(5, 5, 0.05, 3, 1), (8, 8, 0.05, 2, 1), (10, 10, 0.05, 2, 1)]      # reference configs.py:52
+HEAD_NAMES = ['yolov3_head_8', 'yolov3_head_16', 'yolov3_head_32']
+TRAIN_GFLOP_PER_IMAGE = 51.727     # ResNet18 416x416, 80 classes, anchors 3/3/3, fwd + dgrad + wgrad
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md chip-level parameters)
+
+
+def synthetic_batch(N, H, W, class_num, rank, T=8):
+    """images U[0,1) seed 800 (+rank); labels n~U{1..8}, cx,cy~U(.05,.95), w,h~U(.03,.6) clipped, seed 6"""
+    g = torch.Generator().manual_seed(800 + rank)
+    images = torch.rand(N, H, W, 3, generator=g)
+    rng = np.random.RandomState(6 + rank)
+    labels = -np.ones((N, T, 5), dtype=np.float32)
+    for n in range(N):
+        k = rng.randint(1, T + 1)
+        cx, cy = rng.uniform(0.05, 0.95, k), rng.uniform(0.05, 0.95, k)
+        w = np.minimum(rng.uniform(0.03, 0.6, k), 2 * np.minimum(cx, 1 - cx))
+        h = np.minimum(rng.uniform(0.03, 0.6, k), 2 * np.minimum(cy, 1 - cy))
+        labels[n, :k] = np.stack([cx, cy, w, h, rng.randint(0, class_num, k)], axis=1)
+    return images, torch.from_numpy(labels.reshape(N, T * 5))
+
+
+def build_model(backbone, H, W, N, class_num, device):
+    from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
+    from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
+    from yolov3_tensorflow_amd.utils.radam import RAdam
+    L = 5 + class_num
+    chans = [len(a) * L for a in COCO_ANCHORS]
+    grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+    model = YOLOv3Detector(backbone).build((H, W, 3), chans, HEAD_NAMES, batch_size=N, device=device)
+    loss = YOLOv3Loss(grids, class_num, COCO_ANCHORS, 0.8, LOSS_WEIGHTS, rectified_coord_num=-1, rectified_loss_weight=[1.0, 1.0, 1.0])
+    opt = RAdam(lr=1e-3)
+    model.compile(optimizer=opt, loss=loss.loss)
+    return model, loss, opt, grids
+
+
+def conv_kernel_roofline(model, steps):
+    """Average achieved TFLOP/s of the dominant kernel (the implicit-GEMM fwd/dgrad kernel) measured with HIP events on the
+    launch stream in an eager (non-graph) pass: sum of algorithmic FLOPs of its launches / sum of their durations."""
+    from yolov3_tensorflow_amd import engine, ops
+    convs = [op for op in model.g.tape if isinstance(op, engine.ConvOp)]
+    real = {ops.conv2d_fwd: ops.conv2d_fwd, ops.conv2d_dgrad: ops.conv2d_dgrad}
+    records = []
+
+    def timed(fn, flops_of):
+        def wrapper(p, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(p, *a, **k)
+            e1.record()
+            records.append((e0, e1, flops_of(p)))
+        return wrapper
+
+    def flops(p):     # algorithmic: real (unpadded) channels are within 0.4 % of the padded ones except the RGB stem (3 of 8)
+        cin = 3 if p.Cin == 8 else p.Cin
+        return 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S
+
+    ops_fwd, ops_dg = ops.conv2d_fwd, ops.conv2d_dgrad
+    ops.conv2d_fwd, ops.conv2d_dgrad = timed(ops_fwd, flops), timed(ops_dg, flops)
+    try:
+        for _ in range(steps):
+            model._fwd_bwd()
+            model._update()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d_fwd, ops.conv2d_dgrad = ops_fwd, ops_dg
+    t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in records)
+    fl = sum(f for _, _, f in records)
+    return fl / (t_ms * 1e-3) / 1e12, t_ms / max(len(records), 1), len(records) // max(steps, 1)
+
+
+def cpu_baseline(H, W, class_num, budget_batch=4):
+    """the CPU oracle (a restatement of the reference step on PyTorch-CPU, NOT TensorFlow) timed on this host's cores"""
+    from oracle.train import OracleTrainer
+    grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+    images, labels = synthetic_batch(budget_batch, H, W, class_num, 0)
+    o = OracleTrainer('resnet-18', grids, class_num, COCO_ANCHORS, 0.8, LOSS_WEIGHTS, rectified_coord_num=-1)
+    o.ensure_params(images.numpy())
+    o.step(images.numpy(), labels.numpy())        # warm-up step (allocations, thread pools)
+    n_steps, t0 = 0, time.time()
+    while n_steps < 12 and (time.time() - t0 < 12.0 or n_steps < 2):     # ~10-20 s of CPU work
+        o.step(images.numpy(), labels.numpy())
+        n_steps += 1
+    dt = (time.time() - t0) / n_steps
+    return {'value': round(budget_batch / dt, 3), 'unit': 'images/sec', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'sample': '%d timed step(s) of batch %d at %dx%d, %d classes (PyTorch-CPU float32 restatement of the reference step; '
+                      'host has %d logical cpus)' % (n_steps, budget_batch, H, W, class_num, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
+    ap.add_argument('--size', type=int, default=416)
+    ap.add_argument('--classes', type=int, default=80)
+    ap.add_argument('--backbone', default='resnet-18')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda:%d' % local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl')
+
+    H = W = args.size
+    model, loss, opt, grids = build_model(args.backbone, H, W, args.batch, args.classes, device)
+    model.use_hip_graph = not args.no_graph
+    if world > 1:
+        from yolov3_tensorflow_amd import parallel
+        parallel.setup_data_parallel(model)
+    images, labels = synthetic_batch(args.batch, H, W, args.classes, rank)
+    model.stage_batch(images, labels)        # inputs resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.run_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.run_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(model.loss_value.item())
+    if not np.isfinite(final_loss):
+        raise SystemExit('non-finite loss %r' % final_loss)
+
+    ms = elapsed / args.steps * 1e3
+    ips = args.batch * world * args.steps / elapsed
+    gflop = TRAIN_GFLOP_PER_IMAGE if (args.size == 416 and args.classes == 80 and args.backbone == 'resnet-18') else None
+    out = {
+        'metric': 'images/sec training 416x416 ResNet18-YOLOv3 (bf16)',
+        'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+        'data': 'synthetic',
+        'config': {'workload': '%s-YOLOv3 %dx%d, %d classes, anchors 3/3/3 (COCO-9), per-GPU batch %d, full training step '
+                               '(fwd + YOLOv3 loss + bwd + RAdam/L2%s), random-init weights'
+                               % (args.backbone, H, W, args.classes, args.batch, ' + RCCL grad all-reduce' if world > 1 else ''),
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'hip_graph': bool(model.use_hip_graph),
+                   'final_loss': round(final_loss, 4)},
+    }
+    if rank == 0 and gflop is not None:
+        out['step_tflops'] = round(ips / world * gflop / 1000.0, 2)      # per GPU, whole step, algorithmic conv FLOPs
+        out['step_mfma_frac'] = round(out['step_tflops'] / PEAK_BF16_TFLOPS, 4)
+    if rank == 0 and not args.no_roofline:
+        tf, avg_ms, per_step = conv_kernel_roofline(model, max(2, min(5, args.steps)))
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'igemm_fwd_kernel (conv forward + data-gradient launches)', 'achieved': round(tf, 2),
+                           'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                           'avg_launch_ms': round(avg_ms, 5), 'launches_per_step': per_step}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(H, W, args.classes)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
