@@ -137,7 +137,7 @@ typedef struct {
 
 int64_t yolo_loss_workspace_bytes(const yolo_loss_config* c, int N);
 /* logits*: float32 [N][H][W][ldc].  dlogits* (float32, may be NULL) and dlogits*_bf16 (may be NULL) get d(total)/d(logits)
- * in the same layout (padding channels are never written).  current_num: device int32 rectified-image counter (advances by
+ * in the same layout (padding channels are written as zeros).  current_num: device int32 rectified-image counter (advances by
  * batch_global while active).  terms: float32 [6][3] (rows xy, wh, noobj, obj, class, rectified); total: float32 [1].
  * assign_out (int32 [N][T][3], may be NULL): flat index (row*W+col)*B+anchor of the responsible prediction or -1;
  * resp_iou_out (float32 [N][T][3], may be NULL). */

@@ -51,6 +51,38 @@ __global__ __launch_bounds__(EW_THREADS) void bn_stats_kernel(const bf16_t* __re
   block_reduce_store<2>(acc, C, partial);
 }
 
+// Column reduction used by the finalize kernels: one block = 8 channels x 128 row-lanes (1024 threads); lane (rl, c) sums rows
+// rl, rl+128, ... of K quantities in double, then a shared-memory tree over the 128 row-lanes.  (A 32 x 32 shape with one block
+// per 32 channels left a 64-channel layer's 5408 partial rows to 2 workgroups: 42 us of pure load latency per launch.)
+template <int K>
+__device__ __forceinline__ bool column_reduce(const float* const (&src)[K], int P, size_t rstride, int C, double (&tot)[K]) {
+  __shared__ double red[K][128][8];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  double s[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) s[k] = 0.0;
+  if (c < C) {
+    for (int p = rl; p < P; p += 128) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) s[k] += (double)src[k][(size_t)p * rstride + c];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) red[k][rl][cl] = s[k];
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if (rl < o) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) red[k][rl][cl] += red[k][rl + o][cl];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) tot[k] = red[k][0][cl];
+  return rl == 0 && c < C;
+}
+
 // forward finalize: batch mean / biased variance -> scale, shift, mean, rstd; moving statistics (momentum, unbiased var)
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int P,
                                                            size_t rstride, int C, float count, const float* __restrict__ gamma,
@@ -58,32 +90,24 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ moving_mean, float* __restrict__ moving_var,
                                                            float* __restrict__ scale, float* __restrict__ shift,
                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
-  if (c >= C) return;  // C is a multiple of 32: whole block exits together
-  __shared__ double red[2][32][33];
-  double s = 0.0, q = 0.0;
-  for (int p = ry; p < P; p += 32) { s += (double)psum[(size_t)p * rstride + c]; q += (double)psq[(size_t)p * rstride + c]; }
-  red[0][ry][threadIdx.x & 31] = s;
-  red[1][ry][threadIdx.x & 31] = q;
-  __syncthreads();
-  if (ry == 0) {
-    s = 0.0; q = 0.0;
-    for (int r = 0; r < 32; ++r) { s += red[0][r][threadIdx.x & 31]; q += red[1][r][threadIdx.x & 31]; }
-    const double mean = s / (double)count;
-    double var = q / (double)count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float sc = g * rstd;
-    scale[c] = sc;
-    shift[c] = b - (float)mean * sc;
-    mean_o[c] = (float)mean;
-    rstd_o[c] = rstd;
-    if (moving_mean) {
-      const double unb = count > 1.f ? var * ((double)count / ((double)count - 1.0)) : var;
-      moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
-      moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unb;
-    }
+  const float* const src[2] = {psum, psq};
+  double tot[2];
+  if (!column_reduce<2>(src, P, rstride, C, tot)) return;
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  const double mean = tot[0] / (double)count;
+  double var = tot[1] / (double)count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * rstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  mean_o[c] = (float)mean;
+  rstd_o[c] = rstd;
+  if (moving_mean) {
+    const double unb = count > 1.f ? var * ((double)count / ((double)count - 1.0)) : var;
+    moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
+    moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unb;
   }
 }
 
@@ -254,25 +278,14 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(G gp, const b
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, int C, int which, float count,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ k1, float* __restrict__ k2) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
-  if (c >= C) return;
-  __shared__ double red[2][32][33];
-  double s = 0.0, q = 0.0;
-  for (int p = ry; p < P; p += 32) {
-    s += (double)partial[((size_t)p * 3 + 0) * C + c];
-    q += (double)partial[((size_t)p * 3 + which) * C + c];
-  }
-  red[0][ry][threadIdx.x & 31] = s;
-  red[1][ry][threadIdx.x & 31] = q;
-  __syncthreads();
-  if (ry == 0) {
-    s = 0.0; q = 0.0;
-    for (int r = 0; r < 32; ++r) { s += red[0][r][threadIdx.x & 31]; q += red[1][r][threadIdx.x & 31]; }
-    if (dgamma) dgamma[c] = (float)q;
-    if (dbeta) dbeta[c] = (float)s;
-    k1[c] = (float)(s / (double)count);
-    k2[c] = (float)(q / (double)count);
-  }
+  const float* const src[2] = {partial, partial + (size_t)which * C};
+  double tot[2];
+  if (!column_reduce<2>(src, P, (size_t)3 * C, C, tot)) return;
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  if (dgamma) dgamma[c] = (float)tot[1];
+  if (dbeta) dbeta[c] = (float)tot[0];
+  k1[c] = (float)(tot[0] / (double)count);
+  k2[c] = (float)(tot[1] / (double)count);
 }
 
 // dy = a * (g - k1 - xhat * k2), a = gamma * rstd  (a == nullptr: dy = g, no BN);  optional second BN branch (y2 ...);
@@ -385,18 +398,10 @@ __global__ __launch_bounds__(EW_THREADS) void pack_input_kernel(const float* __r
 // ---- out[c] = sum_p partial[p * rstride + c]  (column sums of partial rows; used for the detection-conv bias gradient) ----
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int P, size_t rstride, int C,
                                                                float* __restrict__ out) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
-  __shared__ double red[32][33];
-  double s = 0.0;
-  if (c < C)
-    for (int p = ry; p < P; p += 32) s += (double)part[(size_t)p * rstride + c];
-  red[ry][threadIdx.x & 31] = s;
-  __syncthreads();
-  if (ry == 0 && c < C) {
-    s = 0.0;
-    for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x & 31];
-    out[c] = (float)s;
-  }
+  const float* const src[1] = {part};
+  double tot[1];
+  if (!column_reduce<1>(src, P, rstride, C, tot)) return;
+  out[blockIdx.x * 8 + (threadIdx.x & 7)] = (float)tot[0];
 }
 
 // ---- inference-mode BatchNorm: scale/shift from the moving statistics (keras learning_phase False, run.py:21-24) ----
@@ -423,7 +428,7 @@ inline bool chan_ok(int C) {  // C/8 must divide 256
 inline int reduce_grid(int M, int C) {
   const int RL = EW_THREADS / (C / 8);
   int b = (M + RL - 1) / RL;
-  if (b > 1024) b = 1024;
+  if (b > 512) b = 512;   // 2 workgroups per CU; the finalize kernels then reduce <= 512 partial rows
   if (b < 1) b = 1;
   return b;
 }
@@ -442,9 +447,9 @@ extern "C" int yolo_bn_stats(const void* x, int M, int C, float* partial, void* 
 extern "C" int yolo_bn_finalize(const float* psum, const float* psq, int P, int64_t row_stride, int C, float count,
                                 const float* gamma, const float* beta, float eps, float momentum, float* moving_mean,
                                 float* moving_var, float* scale, float* shift, float* mean, float* rstd, void* stream) {
-  YOLO_CHECK_ARG(psum && psq && scale && shift && mean && rstd && P > 0 && C > 0 && C % 32 == 0 && count > 0.f, "bad argument");
+  YOLO_CHECK_ARG(psum && psq && scale && shift && mean && rstd && P > 0 && C > 0 && count > 0.f, "bad argument");
   YOLO_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "moving_mean and moving_var go together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 32), dim3(1024), 0, (hipStream_t)stream, psum, psq, P, (size_t)row_stride, C, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, psum, psq, P, (size_t)row_stride, C, count,
                      gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
@@ -489,8 +494,8 @@ extern "C" int yolo_bn_act_bwd_reduce(const void* dout, const void* out, int rel
 
 extern "C" int yolo_bn_bwd_finalize(const float* partial, int P, int C, int which, float count, float* dgamma, float* dbeta, float* k1,
                                     float* k2, void* stream) {
-  YOLO_CHECK_ARG(partial && k1 && k2 && P > 0 && C > 0 && C % 32 == 0 && (which == 1 || which == 2) && count > 0.f, "bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32), dim3(1024), 0, (hipStream_t)stream, partial, P, C, which, count, dgamma, dbeta,
+  YOLO_CHECK_ARG(partial && k1 && k2 && P > 0 && C > 0 && (which == 1 || which == 2) && count > 0.f, "bad argument");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, P, C, which, count, dgamma, dbeta,
                      k1, k2);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
@@ -573,7 +578,7 @@ extern "C" int yolo_pack_input(const float* images, void* out, int64_t npix, int
 
 extern "C" int yolo_reduce_partials(const float* partial, int P, int64_t row_stride, int C, float* out, void* stream) {
   YOLO_CHECK_ARG(partial && out && P > 0 && C > 0 && row_stride >= C, "bad argument");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride, C, out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride, C, out);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

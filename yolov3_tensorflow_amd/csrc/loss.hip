@@ -110,6 +110,12 @@ __global__ __launch_bounds__(64) void loss_assign_kernel(LossCfg cfg, const floa
 // ---------------------------------------------------------------------------------------------------------------- 2. main
 constexpr int LM_THREADS = 256;
 
+// LDS budget (floats) of loss_main_kernel for T label slots and channel stride ldc
+__host__ __device__ inline int lm_lds_floats(int T, int ldc) { return T * 10 + ldc / 2 + 4 * 64 * 8 + 4 * 6; }
+
+// One wave = 64/B whole cells (lane -> (cell, anchor)), so the gradient block a wave produces is a run of complete logits rows
+// and is written back with 16-byte (float32) / 8-byte (bf16) stores: lane -> 4 consecutive channels, via an LDS table
+// channel -> (anchor, field).
 __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, const float* __restrict__ l0, const float* __restrict__ l1,
                                                                const float* __restrict__ l2, const float* __restrict__ labels,
                                                                const int* __restrict__ assign, const int* __restrict__ current_num,
@@ -119,14 +125,18 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
   extern __shared__ float sh[];
   const yolo_loss_config& c = cfg.c;
   const int h = blockIdx.y, n = blockIdx.z, T = c.T, L = c.L;
-  const int H = c.H[h], W = c.W[h], B = c.B[h], ldc = c.ldc[h], P = cfg.P[h];
+  const int H = c.H[h], W = c.W[h], B = c.B[h], ldc = c.ldc[h], HW = H * W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // LDS: GT table [T][8] (x0,y0,x1,y1,area,valid,-,-), assignment [T], wave scratch [4][64][5], reduction [4][6]
+  // LDS: GT table [T][8] (x0,y0,x1,y1,area,valid,-,-), assignment [T], GT class [T], channel table [ldc] (u16),
+  //      wave scratch [4][64][8] (g0..g4, softmax max, softmax sum, #responsible GTs or -1), reduction [4][6]
   float* s_gt = sh;
   int* s_as = reinterpret_cast<int*>(sh + T * 8);
-  float* s_w = sh + T * 9 + wave * 64 * 5;
-  float* s_red = sh + T * 9 + 4 * 64 * 5;
+  int* s_cls = reinterpret_cast<int*>(sh + T * 9);
+  unsigned short* s_lut = reinterpret_cast<unsigned short*>(sh + T * 10);
+  float* s_w = sh + T * 10 + ldc / 2 + wave * 64 * 8;
+  float* s_red = sh + T * 10 + ldc / 2 + 4 * 64 * 8;
   const float fW = (float)W, fH = (float)H;
+  const int C = L - 5;
   for (int t = threadIdx.x; t < T; t += LM_THREADS) {
     const float* lab = labels + ((size_t)n * T + t) * 5;
     const float tx = lab[0] * fW, ty = lab[1] * fH, tw = lab[2] * fW, th = lab[3] * fH;
@@ -135,39 +145,48 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
     s_gt[t * 8 + 4] = tw * th;
     s_gt[t * 8 + 5] = lab[0] >= 0.f ? 1.f : 0.f;
     s_as[t] = assign[((size_t)n * T + t) * 3 + h];
+    s_cls[t] = (int)lab[4];
+  }
+  for (int ch = threadIdx.x; ch < ldc; ch += LM_THREADS) {
+    unsigned short e = 0xFFFF;  // padding channel
+    if (ch < B * L) {
+      const int bb = ch / L, j = ch - bb * L;
+      e = (unsigned short)((bb << 8) | (j < 5 ? j : 5));
+    }
+    s_lut[ch] = e;
   }
   __syncthreads();
 
-  const float* lg = (h == 0 ? l0 : (h == 1 ? l1 : l2)) + (size_t)n * H * W * ldc;
+  const float* lg = (h == 0 ? l0 : (h == 1 ? l1 : l2)) + (size_t)n * HW * ldc;
   float* dg = (h == 0 ? d0 : (h == 1 ? d1 : d2));
   bf16_t* eg = (h == 0 ? e0 : (h == 1 ? e1 : e2));
-  if (dg) dg += (size_t)n * H * W * ldc;
-  if (eg) eg += (size_t)n * H * W * ldc;
+  if (dg) dg += (size_t)n * HW * ldc;
+  if (eg) eg += (size_t)n * HW * ldc;
   const bool rect = c.rectified_coord_num >= 0 && current_num[0] <= c.rectified_coord_num;  // yolov3_loss.py:125
   const float eps_lo = c.eps, eps_hi = 1.f - c.eps;
   const float w_xy = c.w_xy[h], w_wh = c.w_wh[h], w_no = c.w_noobj[h], w_obj = c.w_obj[h], w_cls = c.w_cls[h], w_r = c.w_rect[h];
 
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // xy, wh, noobj, obj, class, rectified (un-normalised sums)
-  const int wave_base = (blockIdx.x * (LM_THREADS / 64) + wave) * 64;
-  if (wave_base < P) {  // wave-uniform
-    const int pid = wave_base + lane;
-    const bool pv = pid < P;
+  const int cpw = 64 / B;                            // whole cells per wave
+  const int cell_base = (blockIdx.x * (LM_THREADS / 64) + wave) * cpw;
+  if (cell_base < HW) {  // wave-uniform
+    const int cl = lane / B, b = lane - cl * B;
+    const int cell = cell_base + cl;
+    const bool pv = cl < cpw && cell < HW;
+    const int pid = cell * B + b;
     float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    int nresp = 0;
-    int cell = 0, b = 0;
-    const float* t = lg;
+    float mx = 0.f, se = 1.f, nvalid = -1.f;
     if (pv) {
-      cell = pid / B; b = pid - cell * B;
       const int row = cell / W, col = cell - row * W;
-      t = lg + (size_t)cell * ldc + b * L;
+      const float* t = lg + (size_t)cell * ldc + b * L;
       const float t4[5] = {t[0], t[1], t[2], t[3], t[4]};
-      const float aw = c.anchor_w[h][b], ah = c.anchor_h[h][b];
-      const Box p = decode_box(t4, col, row, aw, ah, eps_lo, eps_hi);
+      const Box p = decode_box(t4, col, row, c.anchor_w[h][b], c.anchor_h[h][b], eps_lo, eps_hi);
       const float sx = sigmoidf_(t4[0]), sy = sigmoidf_(t4[1]);
       const float sc = sigmoidf_(t4[4]);
       const float conf = clipf_(sc, eps_lo, eps_hi);          // yolov3_decoder.py:178-179
       const bool conf_pass = sc >= eps_lo && sc <= eps_hi;    // tf.clip_by_value gradient
       float max_iou = -INFINITY;
+      int nresp = 0;
       for (int k = 0; k < T; ++k) {
         if (s_gt[k * 8 + 5] == 0.f) continue;
         const float v = iou_ref(p.x0, p.y0, p.x1, p.y1, p.area, s_gt[k * 8], s_gt[k * 8 + 1], s_gt[k * 8 + 2], s_gt[k * 8 + 3],
@@ -220,55 +239,63 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
       }
 #pragma unroll
       for (int j = 0; j < 5; ++j) g[j] *= inv_n;
+      // class term of a responsible prediction (:361-364): softmax statistics + loss here, gradient in the store pass
+      if (nresp > 0 && C > 0) {
+        mx = -INFINITY;
+        for (int k = 0; k < C; ++k) mx = fmaxf(mx, t[5 + k]);
+        se = 0.f;
+        for (int k = 0; k < C; ++k) se += expf(t[5 + k] - mx);
+        int nv = 0;
+        for (int k = 0; k < T; ++k) {
+          if (s_as[k] != pid) continue;
+          const int cls = s_cls[k];
+          if (cls >= 0 && cls < C) {
+            acc[4] += -logf(clipf_(expf(t[5 + cls] - mx) / se, eps_lo, eps_hi));
+            ++nv;
+          }
+        }
+        nvalid = (float)nv;
+      }
     }
-    // ---- wave-cooperative store of the 64 x L gradient block ----
 #pragma unroll
-    for (int j = 0; j < 5; ++j) s_w[lane * 5 + j] = g[j];
-    const unsigned long long rmask = __ballot(nresp > 0 && L > 5);
-    // (same-wave LDS write -> read: no barrier needed, but keep the compiler from reordering)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int j = 0; j < 5; ++j) s_w[lane * 8 + j] = g[j];
+    s_w[lane * 8 + 5] = mx; s_w[lane * 8 + 6] = se; s_w[lane * 8 + 7] = nvalid;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // same-wave LDS write -> read by other lanes
     __builtin_amdgcn_wave_barrier();
-    const int cnt = min(64, P - wave_base) * L;
-    for (int i = lane; i < cnt; i += 64) {
-      const int pl = i / L, j = i - pl * L;
-      const int id = wave_base + pl;
-      const int cl = id / B, bb = id - cl * B;
-      const size_t off = (size_t)cl * ldc + bb * L + j;
-      float v = 0.f;
-      if (j < 5) v = s_w[pl * 5 + j];
-      else if ((rmask >> pl) & 1ull) continue;  // class gradients of responsible predictions are written by their own lane
-      if (dg) dg[off] = v;
-      if (eg) eg[off] = f2bf(v);
-    }
-    // ---- class term of responsible predictions (:361-364) ----
-    if (pv && nresp > 0 && L > 5) {
-      const int C = L - 5;
-      float mx = -INFINITY;
-      for (int k = 0; k < C; ++k) mx = fmaxf(mx, t[5 + k]);
-      float se = 0.f;
-      for (int k = 0; k < C; ++k) se += expf(t[5 + k] - mx);
-      for (int k = 0; k < T; ++k) {
-        if (s_as[k] != pid) continue;
-        const int cls = (int)labels[((size_t)n * T + k) * 5 + 4];
-        if (cls >= 0 && cls < C) {
-          const float pr = clipf_(expf(t[5 + cls] - mx) / se, eps_lo, eps_hi);
-          acc[4] += -logf(pr);
+    // ---- store pass: ncell complete rows of ldc channels, 4 channels per lane ----
+    const int ncell = min(cpw, HW - cell_base);
+    const int q = ldc >> 2;  // lanes per row (ldc = 64 * 2^k)
+    const float gscale = w_cls * inv_n;
+    for (int idx = lane; idx < ncell * q; idx += 64) {
+      const int clx = idx / q, c4 = idx - clx * q;
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ch = c4 * 4 + u;
+        const unsigned e = s_lut[ch];
+        v[u] = 0.f;
+        if (e != 0xFFFFu) {
+          const int bb = e >> 8, j = e & 0xFF;
+          const int pl = clx * B + bb;
+          if (j < 5) {
+            v[u] = s_w[pl * 8 + j];
+          } else if (s_w[pl * 8 + 7] >= 0.f) {               // class logit of a responsible prediction: w*(n*softmax - counts)/N
+            const int k = ch - bb * L - 5;
+            const int rpid = (cell_base + clx) * B + bb;
+            const float sm = expf(lg[(size_t)(cell_base + clx) * ldc + ch] - s_w[pl * 8 + 5]) / s_w[pl * 8 + 6];
+            float cnt = 0.f;
+            for (int t2 = 0; t2 < T; ++t2) cnt += (s_as[t2] == rpid && s_cls[t2] == k) ? 1.f : 0.f;
+            v[u] = gscale * (s_w[pl * 8 + 7] * sm - cnt);
+          }
         }
       }
-      const size_t off0 = (size_t)cell * ldc + b * L + 5;
-      for (int k = 0; k < C; ++k) {
-        const float sm = expf(t[5 + k] - mx) / se;
-        float gk = 0.f;
-        for (int q = 0; q < T; ++q) {
-          if (s_as[q] != pid) continue;
-          const int cls = (int)labels[((size_t)n * T + q) * 5 + 4];
-          if (cls < 0 || cls >= C) continue;
-          const float pc = expf(t[5 + cls] - mx) / se;
-          if (pc >= eps_lo && pc <= eps_hi) gk += sm - (k == cls ? 1.f : 0.f);
-        }
-        gk *= w_cls * inv_n;
-        if (dg) dg[off0 + k] = gk;
-        if (eg) eg[off0 + k] = f2bf(gk);
+      const size_t off = (size_t)(cell_base + clx) * ldc + c4 * 4;
+      if (dg) *reinterpret_cast<float4*>(dg + off) = make_float4(v[0], v[1], v[2], v[3]);
+      if (eg) {
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(eg + off) = o;
       }
     }
   }
@@ -286,42 +313,54 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------- 3. finalize
-__global__ __launch_bounds__(64) void loss_finalize_kernel(LossCfg cfg, const float* __restrict__ partial, int N, int nbx, float inv_n,
-                                                           int batch_global, int* __restrict__ current_num, float* __restrict__ terms /*[6][3]*/,
-                                                           float* __restrict__ total) {
+// 18 waves: wave w reduces term k = w / 3 of head h = w % 3 over all images and blocks
+__global__ __launch_bounds__(18 * 64) void loss_finalize_kernel(LossCfg cfg, const float* __restrict__ partial, int N, int nbx, float inv_n,
+                                                                int batch_global, int* __restrict__ current_num, float* __restrict__ terms /*[6][3]*/,
+                                                                float* __restrict__ total) {
   __shared__ float s_t[18];
   const yolo_loss_config& c = cfg.c;
   const bool rect = c.rectified_coord_num >= 0 && current_num[0] <= c.rectified_coord_num;
-  if (threadIdx.x < 18) {
-    const int k = threadIdx.x / 3, h = threadIdx.x - k * 3;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) {  // per-image sums first (the reference reduces per image, then means over the batch)
-      float si = 0.f;
-      for (int b = 0; b < nbx; ++b) si += partial[(((size_t)n * 3 + h) * nbx + b) * 6 + k];
-      s += si;
-    }
-    const float w = (k == 0 ? c.w_xy[h] : k == 1 ? c.w_wh[h] : k == 2 ? c.w_noobj[h] : k == 3 ? c.w_obj[h] : k == 4 ? c.w_cls[h] : c.w_rect[h]);
-    float v = w * s * inv_n;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = w / 3, h = w - k * 3;
+  float s = 0.f;
+  for (int i = lane; i < N * nbx; i += 64) {
+    const int n = i / nbx, b = i - n * nbx;
+    s += partial[(((size_t)n * 3 + h) * nbx + b) * 6 + k];
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float wt = (k == 0 ? c.w_xy[h] : k == 1 ? c.w_wh[h] : k == 2 ? c.w_noobj[h] : k == 3 ? c.w_obj[h] : k == 4 ? c.w_cls[h] : c.w_rect[h]);
+    float v = wt * s * inv_n;
     if (k == 5 && !rect) v = 0.f;
-    s_t[threadIdx.x] = v;
-    terms[threadIdx.x] = v;
+    s_t[w] = v;
+    terms[w] = v;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < 18; ++i) s += s_t[i];
-    total[0] = s;
+    float t = 0.f;
+    for (int i = 0; i < 18; ++i) t += s_t[i];
+    total[0] = t;
     if (rect) current_num[0] += batch_global;  // yolov3_loss.py:152 (advances only while the rectified branch is taken)
   }
+}
+
+inline int loss_nbx(const yolo_loss_config* c) {
+  int nbx = 1;
+  for (int h = 0; h < 3; ++h) {
+    const int cells_per_block = (LM_THREADS / 64) * (64 / c->B[h]);
+    const int nb = (c->H[h] * c->W[h] + cells_per_block - 1) / cells_per_block;
+    nbx = nb > nbx ? nb : nbx;
+  }
+  return nbx;
 }
 
 }  // namespace
 
 extern "C" int64_t yolo_loss_workspace_bytes(const yolo_loss_config* c, int N) {
   if (!c || N <= 0 || c->T <= 0) return YOLO_ERR_INVALID_ARG;
-  int maxP = 0;
-  for (int h = 0; h < 3; ++h) maxP = maxP > c->H[h] * c->W[h] * c->B[h] ? maxP : c->H[h] * c->W[h] * c->B[h];
-  const int nbx = (maxP + LM_THREADS - 1) / LM_THREADS;
+  for (int h = 0; h < 3; ++h)
+    if (c->B[h] <= 0 || c->B[h] > YOLO_MAX_ANCHORS || c->H[h] <= 0 || c->W[h] <= 0) return YOLO_ERR_INVALID_ARG;
+  const int nbx = loss_nbx(c);
   return (int64_t)N * c->T * 3 * 4 /*assign*/ + (int64_t)N * 3 * nbx * 6 * 4 /*partials*/;
 }
 
@@ -334,15 +373,16 @@ extern "C" int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_glo
   YOLO_CHECK_ARG(c->T > 0 && c->T <= 512 && c->L >= 5 && c->L <= 4096, "bad T / L");
   LossCfg cfg;
   cfg.c = *c;
-  int maxP = 0;
+  int max_ldc = 0;
   for (int h = 0; h < 3; ++h) {
     YOLO_CHECK_ARG(c->H[h] > 0 && c->W[h] > 0 && c->B[h] > 0 && c->B[h] <= YOLO_MAX_ANCHORS, "bad head geometry");
     YOLO_CHECK_ARG(c->ldc[h] >= c->B[h] * c->L, "ldc smaller than B*L");
+    YOLO_CHECK_ARG(c->ldc[h] >= 64 && (c->ldc[h] & (c->ldc[h] - 1)) == 0, "ldc must be a power of two >= 64");
     cfg.P[h] = c->H[h] * c->W[h] * c->B[h];
     cfg.area[h] = (float)(c->H[h] * c->W[h]);
-    maxP = maxP > cfg.P[h] ? maxP : cfg.P[h];
+    max_ldc = max_ldc > c->ldc[h] ? max_ldc : c->ldc[h];
   }
-  const int nbx = (maxP + LM_THREADS - 1) / LM_THREADS;
+  const int nbx = loss_nbx(c);
   int* assign = assign_out ? assign_out : reinterpret_cast<int*>(workspace);
   float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (size_t)N * c->T * 3 * 4);
   hipStream_t st = (hipStream_t)stream;
@@ -350,12 +390,13 @@ extern "C" int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_glo
   hipLaunchKernelGGL(loss_assign_kernel, dim3(N), dim3(64), (size_t)c->T * 3 * 2 * 4, st, cfg, logits8, logits16, logits32, labels, assign,
                      resp_iou_out);
   YOLO_LAUNCH_CHECK();
-  const size_t lds = ((size_t)c->T * 9 + 4 * 64 * 5 + 4 * 6) * 4;
+  const size_t lds = (size_t)lm_lds_floats(c->T, max_ldc) * 4;
+  YOLO_CHECK_ARG(lds <= 64 * 1024, "T / ldc too large for the loss kernel's LDS budget");
   hipLaunchKernelGGL(loss_main_kernel, dim3(nbx, 3, N), dim3(LM_THREADS), lds, st, cfg, logits8, logits16, logits32, labels, assign,
                      current_num, dlogits8, dlogits16, dlogits32, (bf16_t*)dlogits8_bf16, (bf16_t*)dlogits16_bf16, (bf16_t*)dlogits32_bf16,
                      partial, inv_n);
   YOLO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, cfg, partial, N, nbx, inv_n, batch_global, current_num, terms, total);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(18 * 64), 0, st, cfg, partial, N, nbx, inv_n, batch_global, current_num, terms, total);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
