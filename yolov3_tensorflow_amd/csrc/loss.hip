@@ -313,27 +313,29 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------- 3. finalize
-// 18 waves: wave w reduces term k = w / 3 of head h = w % 3 over all images and blocks
-__global__ __launch_bounds__(18 * 64) void loss_finalize_kernel(LossCfg cfg, const float* __restrict__ partial, int N, int nbx, float inv_n,
-                                                                int batch_global, int* __restrict__ current_num, float* __restrict__ terms /*[6][3]*/,
-                                                                float* __restrict__ total) {
+// 9 waves, two outputs each: output o = term k = o / 3 of head h = o % 3, reduced over all images and blocks
+__global__ __launch_bounds__(9 * 64) void loss_finalize_kernel(LossCfg cfg, const float* __restrict__ partial, int N, int nbx, float inv_n,
+                                                               int batch_global, int* __restrict__ current_num, float* __restrict__ terms /*[6][3]*/,
+                                                               float* __restrict__ total) {
   __shared__ float s_t[18];
   const yolo_loss_config& c = cfg.c;
   const bool rect = c.rectified_coord_num >= 0 && current_num[0] <= c.rectified_coord_num;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = w / 3, h = w - k * 3;
-  float s = 0.f;
-  for (int i = lane; i < N * nbx; i += 64) {
-    const int n = i / nbx, b = i - n * nbx;
-    s += partial[(((size_t)n * 3 + h) * nbx + b) * 6 + k];
-  }
-  s = wave_sum(s);
-  if (lane == 0) {
-    const float wt = (k == 0 ? c.w_xy[h] : k == 1 ? c.w_wh[h] : k == 2 ? c.w_noobj[h] : k == 3 ? c.w_obj[h] : k == 4 ? c.w_cls[h] : c.w_rect[h]);
-    float v = wt * s * inv_n;
-    if (k == 5 && !rect) v = 0.f;
-    s_t[w] = v;
-    terms[w] = v;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int o = wave; o < 18; o += 9) {
+    const int k = o / 3, h = o - k * 3;
+    float s = 0.f;
+    for (int i = lane; i < N * nbx; i += 64) {
+      const int n = i / nbx, b = i - n * nbx;
+      s += partial[(((size_t)n * 3 + h) * nbx + b) * 6 + k];
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      const float wt = (k == 0 ? c.w_xy[h] : k == 1 ? c.w_wh[h] : k == 2 ? c.w_noobj[h] : k == 3 ? c.w_obj[h] : k == 4 ? c.w_cls[h] : c.w_rect[h]);
+      float v = wt * s * inv_n;
+      if (k == 5 && !rect) v = 0.f;
+      s_t[o] = v;
+      terms[o] = v;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -396,7 +398,7 @@ extern "C" int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_glo
                      current_num, dlogits8, dlogits16, dlogits32, (bf16_t*)dlogits8_bf16, (bf16_t*)dlogits16_bf16, (bf16_t*)dlogits32_bf16,
                      partial, inv_n);
   YOLO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(18 * 64), 0, st, cfg, partial, N, nbx, inv_n, batch_global, current_num, terms, total);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(9 * 64), 0, st, cfg, partial, N, nbx, inv_n, batch_global, current_num, terms, total);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
