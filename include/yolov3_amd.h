@@ -87,9 +87,10 @@ int yolo_bn_pool_fwd(const void* y, const float* scale, const float* shift, void
 /* g = dout * (out > 0 if relu); partial[rows][3][C] = (sum g, sum g*xhat(y), sum g*xhat(y2)) */
 int yolo_bn_act_bwd_reduce(const void* dout, const void* out, int relu, const void* y, const float* mean, const float* rstd,
                            const void* y2, const float* mean2, const float* rstd2, int M, int C, float* partial, void* stream);
-/* dgamma = sum g*xhat, dbeta = sum g (NULL = skip), k1 = dbeta/count, k2 = dgamma/count; which = 1 (y) or 2 (y2) */
-int yolo_bn_bwd_finalize(const float* partial, int P, int C, int which, float count, float* dgamma, float* dbeta, float* k1, float* k2,
-                         void* stream);
+/* reduce partial rows (row_stride floats apart; quantity q starts q*q_stride floats into a row; the caller may offset `partial` to a
+ * channel sub-range): dgamma = sum g*xhat, dbeta = sum g (NULL = skip), k1 = dbeta/count, k2 = dgamma/count; which = 1 (y) or 2 (y2) */
+int yolo_bn_bwd_finalize(const float* partial, int P, int64_t row_stride, int64_t q_stride, int C, int which, float count,
+                         float* dgamma, float* dbeta, float* k1, float* k2, void* stream);
 /* dy (=|+=) a1*(g - k1 - xhat*k2) (a1 NULL: dy = g); optional second BN branch -> dy2; optional dres (=|+=) g */
 int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu, const void* y, const float* a1, const float* mean,
                           const float* rstd, const float* k1, const float* k2, void* dy, int acc_dy, const void* y2, const float* a2,
@@ -112,6 +113,24 @@ int yolo_bn_eval_scale_shift(const float* gamma, const float* beta, const float*
                              float* scale, float* shift, int C, void* stream);
 /* float32 NHWC images (C = 3, [0,1], BGR: /root/reference/dataset/file_util.py:58-59) -> bf16 NHWC8, channels 3..7 zero */
 int yolo_pack_input(const float* images, void* out, int64_t npix, int Cimg, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Mixed depthwise convolution of MixNet-18: channel groups split[g]..split[g+1] use a ksize[g] x ksize[g] depthwise kernel
+ * (stride 1, 'same').  Replaces the Lambda slices + 4 DepthwiseConv2D + Concatenate of /root/reference/backbone/mixnet18.py:38-45
+ * (factory /root/reference/backbone/basic_backbone.py:45-66) and their TF gradients.  x, y: bf16 [N,H,W,C]; w_g: bf16
+ * [k][k][C_g]; dw_g: float32, atomically accumulated.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t N, H, W, C;
+  int32_t split[5];    /* 0 = split[0] <= ... <= split[4] = C, group sizes multiples of 8 (and /8 a power of two) */
+  int32_t ksize[4];    /* odd, <= 9 */
+} yolo_mixconv_problem;
+int yolo_dwconv_mix_fwd(const yolo_mixconv_problem* p, const void* x, const void* w0, const void* w1, const void* w2, const void* w3,
+                        void* y, void* stream);
+int yolo_dwconv_mix_dgrad(const yolo_mixconv_problem* p, const void* dy, const void* w0, const void* w1, const void* w2, const void* w3,
+                          void* dx, int accumulate, void* stream);
+int yolo_dwconv_mix_wgrad(const yolo_mixconv_problem* p, const void* x, const void* dy, float* dw0, float* dw1, float* dw2, float* dw3,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * YOLOv3 loss forward + backward.  Replaces YOLOv3Decoder.decode (/root/reference/yolov3/yolov3_decoder.py:62-192),

@@ -280,6 +280,41 @@ def test_bn_pool_relu_fwd_bwd(dev):
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize('f', [64, 128])
+def test_mixconv_fwd_dgrad_wgrad(dev, f):
+    """mixed depthwise conv (mixnet18.py:38-45) vs 4 x F.conv2d(groups=C_g) on channel slices"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 2, 11, 9
+    split = [0, f // 2, 3 * f // 4, 7 * f // 8, f]
+    ks = [3, 5, 7, 9]
+    x = bf(torch.randn(N, H, W, f, generator=g))
+    ws = [bf(torch.randn(k, k, split[i + 1] - split[i], generator=g) * (1.0 / k)) for i, k in enumerate(ks)]
+    xr = x.float().requires_grad_(True)
+    wr = [w.float().requires_grad_(True) for w in ws]
+    outs = []
+    for i, k in enumerate(ks):
+        xs = xr[..., split[i]:split[i + 1]].permute(0, 3, 1, 2)
+        cg = split[i + 1] - split[i]
+        outs.append(F.conv2d(xs, wr[i].permute(2, 0, 1).unsqueeze(1), padding=k // 2, groups=cg).permute(0, 2, 3, 1))
+    y_ref = torch.cat(outs, dim=-1)
+    dy = bf(torch.randn(N, H, W, f, generator=g))
+    y_ref.backward(dy.float())
+    p = ops.mix_problem(N, H, W, f, split, ks)
+    d = lambda t: t.to(dev)
+    y = torch.empty(N, H, W, f, dtype=torch.bfloat16, device=dev)
+    wd = [d(w) for w in ws]
+    ops.dwconv_mix_fwd(p, d(x), wd, y)
+    torch.testing.assert_close(y.float().cpu(), y_ref.detach(), rtol=1e-2, atol=1e-2)
+    dx = torch.full((N, H, W, f), 0.5, dtype=torch.bfloat16, device=dev)
+    ops.dwconv_mix_dgrad(p, d(dy), wd, dx, accumulate=True)
+    torch.testing.assert_close(dx.float().cpu(), xr.grad + 0.5, rtol=1e-2, atol=2e-2)
+    dw = [torch.zeros(k, k, split[i + 1] - split[i], device=dev) for i, k in enumerate(ks)]
+    ops.dwconv_mix_wgrad(p, d(x), d(dy), dw)
+    for a, b in zip(dw, wr):
+        torch.testing.assert_close(a.cpu(), b.grad, rtol=1e-3, atol=1e-3)
+
+
 def test_pack_input(dev):
     from yolov3_tensorflow_amd import ops
     img = torch.rand(2, 6, 5, 3)

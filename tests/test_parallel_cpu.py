@@ -1,0 +1,86 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel host logic: weight broadcast from rank 0, SUM all-reduce of the flat gradient and
+the 1/world scaling folded into the optimizer, checked against the single-process reference semantics (keras multi_gpu_model,
+trainer.py:40-43: per-tower BatchNorm, one loss = mean over the concatenated batch => gradient = average of the tower gradients)."""
+import os
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _FakeBN(object):
+    def __init__(self, c):
+        self.moving_mean, self.moving_var = torch.zeros(c), torch.ones(c)
+
+
+class _FakePS(object):
+    def __init__(self, n, rank):
+        g = torch.Generator().manual_seed(100 + rank)
+        self.flat = torch.randn(n, generator=g)
+        self.grad = torch.zeros(n)
+        self.bf16 = torch.zeros(n, dtype=torch.bfloat16)
+        self.n = n
+
+
+class _FakeGraph(object):
+    def __init__(self, n, rank):
+        self.ps = _FakePS(n, rank)
+        self.bns = [_FakeBN(4)]
+
+    def refresh_dgrad_weights(self):
+        pass
+
+
+class _FakeModel(object):
+    def __init__(self, n, rank):
+        self.g = _FakeGraph(n, rank)
+        self.device = torch.device('cpu')
+        self.world_size, self.rank, self.process_group = 1, 0, None
+
+    def set_distributed(self, w, r, pg=None):
+        self.world_size, self.rank, self.process_group = w, r, pg
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank))
+    import contextlib
+    from yolov3_tensorflow_amd import parallel, ops
+    ops.cast_f32_to_bf16 = lambda x, y, n: y.copy_(x.to(torch.bfloat16))          # the only kernel touched by broadcast_weights
+    torch.cuda.device = lambda d: contextlib.nullcontext()
+    m = _FakeModel(1024, rank)
+    m.g.bns[0].moving_mean += rank
+    assert parallel.setup_data_parallel(m, backend='gloo')
+    assert (m.world_size, m.rank) == (world, rank)
+    w_after = m.g.ps.flat.clone()
+    # each rank's "tower gradient" on its half of the batch
+    gen = torch.Generator().manual_seed(7 + rank)
+    tower = torch.randn(1024, generator=gen)
+    m.g.ps.grad.copy_(tower)
+    dist.all_reduce(m.g.ps.grad, op=dist.ReduceOp.SUM)
+    scaled = m.g.ps.grad * (1.0 / m.world_size)                                    # grad_scale of yolo_radam_l2_step
+    out[rank] = (w_after.numpy(), m.g.bns[0].moving_mean.numpy().copy(), tower.numpy(), scaled.numpy(), m.g.ps.bf16.float().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_broadcast_and_average():
+    world, port = 2, 29731
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    w0, bn0, t0, s0, b0 = out[0]
+    w1, bn1, t1, s1, b1 = out[1]
+    np.testing.assert_array_equal(w0, w1)                       # all ranks start from rank 0's weights
+    np.testing.assert_array_equal(bn0, bn1)
+    np.testing.assert_array_equal(bn0, np.zeros(4, np.float32))
+    np.testing.assert_array_equal(b0, torch.from_numpy(w0).to(torch.bfloat16).float().numpy())
+    np.testing.assert_allclose(s0, (t0 + t1) / 2, rtol=1e-6)    # average of the tower gradients, identical on every rank
+    np.testing.assert_array_equal(s0, s1)
+
+
+def test_single_process_is_a_noop(monkeypatch):
+    from yolov3_tensorflow_amd import parallel
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    m = _FakeModel(256, 0)
+    assert parallel.setup_data_parallel(m) is False and m.world_size == 1

@@ -49,7 +49,7 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
 
 
-@pytest.mark.parametrize('backbone,rect', [('resnet-18', -1), ('resnet-18', 1464), ('resnet-18-v2', -1)])
+@pytest.mark.parametrize('backbone,rect', [('resnet-18', -1), ('resnet-18', 1464), ('resnet-18-v2', -1), ('mixnet-18', -1)])
 def test_forward_loss_grads_and_step(backbone, rect):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
@@ -110,7 +110,7 @@ def test_forward_loss_grads_and_step(backbone, rect):
     from yolov3_tensorflow_amd import engine
     inject = []
     for op in model.g.tape:
-        if isinstance(op, engine.ConvOp):
+        if isinstance(op, (engine.ConvOp, engine.MixConvOp)):
             if not op.y.f32:
                 inject.append(op.y.buf.float().cpu())
         else:
@@ -128,6 +128,8 @@ def test_forward_loss_grads_and_step(backbone, rect):
         t = grad_flat[p.offset:p.offset + p.numel]
         if p.kind in ('conv_kernel', 'head_kernel'):
             g_gpu = engine.Graph.kernel_from_dev(t, p).numpy()
+        elif p.kind == 'dw_kernel':
+            g_gpu = engine.Graph.dw_from_dev(t, p).numpy()
         else:
             g_gpu = t[:p.tf_shape[0]].numpy()
         g_ref = oi.det.params.p[p.name].grad.detach().numpy().reshape(g_gpu.shape)

@@ -16,6 +16,10 @@ class ConvProblem(C.Structure):
                 ('N', 'H', 'W', 'Cin', 'C0', 'Cout', 'R', 'S', 'stride', 'pad_t', 'pad_l', 'Ho', 'Wo')]
 
 
+class MixProblem(C.Structure):
+    _fields_ = [('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32), ('split', C.c_int32 * 5), ('ksize', C.c_int32 * 4)]
+
+
 class LossConfig(C.Structure):
     _fields_ = [('H', C.c_int32 * 3), ('W', C.c_int32 * 3), ('B', C.c_int32 * 3), ('ldc', C.c_int32 * 3),
                 ('anchor_w', (C.c_float * MAX_ANCHORS) * 3), ('anchor_h', (C.c_float * MAX_ANCHORS) * 3),
@@ -28,6 +32,7 @@ class LossConfig(C.Structure):
 
 P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 CP = C.POINTER(ConvProblem)
+MP = C.POINTER(MixProblem)
 LP = C.POINTER(LossConfig)
 
 # name -> (restype, argtypes); must list every function declared in include/yolov3_amd.h
@@ -45,7 +50,7 @@ SIGNATURES = {
     'yolo_bn_act_fwd': (I, [P, P, P, P, P, P, P, I64, I, I, P]),
     'yolo_bn_pool_fwd': (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     'yolo_bn_act_bwd_reduce': (I, [P, P, I, P, P, P, P, P, P, I, I, P, P]),
-    'yolo_bn_bwd_finalize': (I, [P, I, I, I, F, P, P, P, P, P]),
+    'yolo_bn_bwd_finalize': (I, [P, I, I64, I64, I, I, F, P, P, P, P, P]),
     'yolo_bn_act_bwd_apply': (I, [P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I64, I, P]),
     'yolo_bn_pool_bwd_reduce': (I, [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P, P]),
     'yolo_bn_pool_bwd_apply': (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
@@ -53,6 +58,9 @@ SIGNATURES = {
     'yolo_pack_input': (I, [P, P, I64, I, P]),
     'yolo_reduce_partials': (I, [P, I, I64, I, P, P]),
     'yolo_bn_eval_scale_shift': (I, [P, P, P, P, F, P, P, I, P]),
+    'yolo_dwconv_mix_fwd': (I, [MP, P, P, P, P, P, P, P]),
+    'yolo_dwconv_mix_dgrad': (I, [MP, P, P, P, P, P, P, I, P]),
+    'yolo_dwconv_mix_wgrad': (I, [MP, P, P, P, P, P, P, P]),
     'yolo_loss_workspace_bytes': (I64, [LP, I]),
     'yolo_loss_fwd_bwd': (I, [LP, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'yolo_radam_schedule': (I, [P, P, F, F, F, F, P]),

@@ -275,12 +275,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(G gp, const b
 
 // backward finalize: dgamma = sum g*xhat, dbeta = sum g (written to the flat gradient buffer), and the two per-channel
 // constants of the apply pass k1 = dbeta / M, k2 = dgamma / M.  which = 1 (main branch) or 2 (shortcut BN, uses quantity 2).
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, int C, int which, float count,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, size_t rstride, size_t qstride, int C,
+                                                               int which, float count, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ k1, float* __restrict__ k2) {
-  const float* const src[2] = {partial, partial + (size_t)which * C};
+  const float* const src[2] = {partial, partial + (size_t)which * qstride};
   double tot[2];
-  if (!column_reduce<2>(src, P, (size_t)3 * C, C, tot)) return;
+  if (!column_reduce<2>(src, P, rstride, C, tot)) return;
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   if (dgamma) dgamma[c] = (float)tot[1];
   if (dbeta) dbeta[c] = (float)tot[0];
@@ -492,11 +492,12 @@ extern "C" int yolo_bn_act_bwd_reduce(const void* dout, const void* out, int rel
   return YOLO_OK;
 }
 
-extern "C" int yolo_bn_bwd_finalize(const float* partial, int P, int C, int which, float count, float* dgamma, float* dbeta, float* k1,
-                                    float* k2, void* stream) {
+extern "C" int yolo_bn_bwd_finalize(const float* partial, int P, int64_t row_stride, int64_t q_stride, int C, int which, float count,
+                                    float* dgamma, float* dbeta, float* k1, float* k2, void* stream) {
   YOLO_CHECK_ARG(partial && k1 && k2 && P > 0 && C > 0 && (which == 1 || which == 2) && count > 0.f, "bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, P, C, which, count, dgamma, dbeta,
-                     k1, k2);
+  YOLO_CHECK_ARG(q_stride >= C && row_stride >= 3 * q_stride, "bad strides");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,
+                     (size_t)q_stride, C, which, count, dgamma, dbeta, k1, k2);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

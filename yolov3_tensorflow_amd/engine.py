@@ -89,6 +89,8 @@ class ParamStore(object):
 
 
 class BNState(object):
+    """one keras BatchNormalization: gamma/beta slots of the flat buffers + per-channel work vectors"""
+
     def __init__(self, g, name, C):
         self.name, self.C = name, C
         ps = g.ps
@@ -96,12 +98,51 @@ class BNState(object):
         self.beta = ps.add(Param(name + '/beta', 'bn_beta', (C,), (C,), 0.0), torch.zeros(C))
         ps.state[name + '/moving_mean'] = self
         ps.state[name + '/moving_variance'] = self
+        self.parts = [(self, 0)]
 
-    def allocate(self, dev):
+    def allocate(self, dev, ps, work=None, c0=0):
         C = self.C
         self.moving_mean = torch.zeros(C, device=dev)
         self.moving_var = torch.ones(C, device=dev)
-        (self.scale, self.shift, self.mean, self.rstd, self.k1, self.k2) = [torch.zeros(C, device=dev) for _ in range(6)]
+        if work is None:
+            work = [torch.zeros(C, device=dev) for _ in range(6)]
+        (self.scale, self.shift, self.mean, self.rstd, self.k1, self.k2) = [w[c0:c0 + C] for w in work]
+        self.v_gamma, self.v_beta = ps.view(self.gamma), ps.view(self.beta)
+        self.v_dgamma, self.v_dbeta = ps.view(self.gamma, ps.grad), ps.view(self.beta, ps.grad)
+
+    # psum / psq: flat float32 tensors whose element [p * row_stride + c] is the partial of row p, channel c
+    def fwd_finalize(self, psum, psq, P, row_stride, count, training):
+        for bn, c0 in self.parts:
+            if training:
+                ops.bn_finalize(psum[c0:], psq[c0:], P, row_stride, bn.C, count, bn.v_gamma, bn.v_beta, BN_EPSILON, BN_MOMENTUM,
+                                bn.moving_mean, bn.moving_var, bn.scale, bn.shift, bn.mean, bn.rstd)
+            else:           # keras learning_phase False (run.py:21-24): normalise with the moving statistics
+                ops.bn_eval_scale_shift(bn.v_gamma, bn.v_beta, bn.moving_mean, bn.moving_var, BN_EPSILON, bn.scale, bn.shift, bn.C)
+
+    # partial: flat float32 view of [P][3][Cfull]
+    def bwd_finalize(self, partial, P, Cfull, which, count):
+        for bn, c0 in self.parts:
+            ops.bn_bwd_finalize(partial[c0:], P, bn.C, which, count, bn.v_dgamma, bn.v_dbeta, bn.k1, bn.k2, row_stride=3 * Cfull,
+                                q_stride=Cfull)
+
+
+class MultiBN(object):
+    """the 4 BatchNorms that follow the 4 depthwise convs of a MixNet block (mixnet18.py:43): per-channel statistics of the
+    concatenated tensor are the same numbers, so they share [C] work vectors and one apply pass; only gamma/beta are separate"""
+
+    def __init__(self, bns, split):
+        self.C = split[-1]
+        self.parts = [(bn, c0) for bn, c0 in zip(bns, split[:-1]) if bn.C > 0]
+        self.name = bns[0].name
+
+    def allocate(self, dev, ps):
+        work = [torch.zeros(self.C, device=dev) for _ in range(6)]
+        (self.scale, self.shift, self.mean, self.rstd, self.k1, self.k2) = work
+        for bn, c0 in self.parts:
+            bn.allocate(dev, ps, work, c0)
+
+    fwd_finalize = BNState.fwd_finalize
+    bwd_finalize = BNState.bwd_finalize
 
 
 class Val(object):
@@ -128,7 +169,8 @@ class Graph(object):
         self.ps = ParamStore(seed)
         self.tape = []
         self.vals = []
-        self.bns = []
+        self.bns = []            # every keras BatchNormalization (for checkpoints)
+        self.bn_groups = []      # allocation units: a BNState or a MultiBN
         self.fwd, self.bwd = [], []
         self.training = True
         self._alloc = []
@@ -204,6 +246,7 @@ class Graph(object):
         C = x.shape[3]
         bn = BNState(self, self.ps.layer_name('batch_normalization_v1'), C)
         self.bns.append(bn)
+        self.bn_groups.append(bn)
         if x.kind == 'conv':
             x.wants_stats = True
         return Val(self, 'bn', x.shape, src=x, bn=bn)
@@ -233,6 +276,38 @@ class Graph(object):
         if b.kind != 'act':
             b = self.materialize(b, relu=False)
         return Val(self, 'cat', b.shape[:3] + (a.shape[3] + b.shape[3],), a=a, b=b)
+
+    def mix_depthwise_conv_bn(self, x, split, ksizes):
+        """4 x (channel slice -> DepthwiseConv2D(k) -> BatchNormalization) -> concat (mixnet18.py:38-45) as one depthwise launch
+        + one grouped BatchNorm.  Variables are created in the reference's order: dw_0, bn_0, dw_1, bn_1, ..."""
+        x = self.materialize(x, relu=False)
+        N, H, W, C = x.shape
+        wps, bns = [], []
+        for i, k in enumerate(ksizes):
+            cg = split[i + 1] - split[i]
+            name = self.ps.layer_name('depthwise_conv2d')
+            w = self.ps.he_normal((k, k, cg, 1), k * k * cg)              # keras he_normal fan_in of a (k,k,Cg,1) kernel
+            wp = Param(name + '/depthwise_kernel', 'dw_kernel', (k, k, cg, 1), (k, k, cg), L2_CONV_DECAY)
+            self.ps.add(wp, w.reshape(k, k, cg))
+            wps.append(wp)
+            bn = BNState(self, self.ps.layer_name('batch_normalization_v1'), cg)
+            self.bns.append(bn)
+            bns.append(bn)
+        mbn = MultiBN(bns, split)
+        self.bn_groups.append(mbn)
+        y = Val(self, 'conv', (N, H, W, C), x=x, wps=wps, mp=ops.mix_problem(N, H, W, C, split, ksizes), f32=False)
+        y.cell = self._buffer(y.shape)
+        y.dy_cell = self._buffer(y.shape)
+        self.tape.append(MixConvOp(self, y))
+        return Val(self, 'bn', y.shape, src=y, bn=mbn)
+
+    @staticmethod
+    def dw_to_dev(w, wp):
+        return w.reshape(wp.dev_shape)
+
+    @staticmethod
+    def dw_from_dev(w_dev, wp):
+        return w_dev.reshape(wp.tf_shape).contiguous()
 
     # ------------------------------------------------------------------------------------------------ lowering
     def materialize(self, v, relu):
@@ -268,8 +343,8 @@ class Graph(object):
         self.ps.allocate(dev)
         for cell, shape, dtype in self._alloc:
             cell['t'] = torch.zeros(shape, dtype=dtype, device=dev)
-        for bn in self.bns:
-            bn.allocate(dev)
+        for bn in self.bn_groups:
+            bn.allocate(dev, self.ps)
         N, H, W, C = self.input_val.shape
         self.images = torch.zeros(N, H, W, C, device=dev)
         self.input_val.buf = torch.zeros(N, H, W, 8, dtype=torch.bfloat16, device=dev)
@@ -322,11 +397,12 @@ class ConvOp(object):
         self.dw = ps.view(y.wp, ps.grad)
         self.bias = ps.view(y.bp) if y.bp is not None else None
         self.dbias = ps.view(y.bp, ps.grad) if y.bp is not None else None
+        self.ssum = self.ssq = None
         if y.stat_cell is not None and y.wants_stats:
             st = y.stat_cell['t']
             self.ssum, self.ssq = st[0], st[1]
-        else:
-            self.ssum = self.ssq = None
+            C = y.shape[3]
+            y.stats = (st[0].view(-1), st[1].view(-1), y.stat_rows, C)        # (psum, psq, P, row_stride)
         x = y.x
         if x.kind == 'cat':
             self.src0, self.src1 = x.a.src, x.b
@@ -359,6 +435,9 @@ class ConvOp(object):
             a, b = x.a.src, x.b
             self.acc = [a.grad_init, b.grad_init]
             a.grad_init = b.grad_init = True
+            import copy
+            self.pd = copy.copy(y.p)
+            self.pd.C0 = 0
         else:
             self.acc = [x.grad_init]
             x.grad_init = True
@@ -375,10 +454,7 @@ class ConvOp(object):
             return
         x = y.x
         if x.kind == 'cat':
-            import copy
-            pd = copy.copy(y.p)
-            pd.C0 = 0
-            ops.conv2d_dgrad(pd, y.dy, self.w_dg, self.dcat)
+            ops.conv2d_dgrad(self.pd, y.dy, self.w_dg, self.dcat)
             a, b = x.a.src, x.b
             N, H, W, _ = x.shape
             ops.upcat_split_bwd(self.dcat, a.grad, self.acc[0], b.grad, self.acc[1], N, H, W, a.shape[3], b.shape[3])
@@ -386,8 +462,43 @@ class ConvOp(object):
             ops.conv2d_dgrad(y.p, y.dy, self.w_dg, x.grad, accumulate=self.acc[0])
 
 
+class MixConvOp(object):
+    """mixed depthwise conv (one launch for the 4 kernel sizes) + per-channel statistics for the grouped BatchNorm"""
+
+    def __init__(self, g, y):
+        self.g, self.y = g, y
+
+    def bind(self):
+        g, y = self.g, self.y
+        y.buf = y.cell['t']
+        y.dy = y.dy_cell['t']
+        ps = g.ps
+        self.w = [ps.view(wp, ps.bf16) for wp in y.wps]
+        self.dw = [ps.view(wp, ps.grad) for wp in y.wps]
+        C = y.shape[3]
+        self.P = ops.reduce_rows(y.M, C)
+        self.part = torch.zeros(self.P, 2, C, device=g.dev)
+        flat = self.part.view(-1)
+        y.stats = (flat, flat[C:], self.P, 2 * C)
+
+    def forward(self):
+        y = self.y
+        ops.dwconv_mix_fwd(y.mp, y.x.buf, self.w, y.buf)
+        ops.bn_stats(y.buf, y.M, y.shape[3], self.part)
+
+    def plan_backward(self):
+        x = self.y.x
+        self.acc = x.grad_init
+        x.grad_init = True
+
+    def backward(self):
+        y = self.y
+        ops.dwconv_mix_wgrad(y.mp, y.x.buf, y.dy, self.dw)
+        ops.dwconv_mix_dgrad(y.mp, y.dy, self.w, y.x.grad, accumulate=self.acc)
+
+
 def _branch(v):
-    """decompose an apply operand into (tensor value, bn state or None)"""
+    """decompose an apply operand into (tensor value, bn object or None)"""
     if v.kind == 'bn':
         return v.src, v.bn
     return v, None
@@ -411,29 +522,20 @@ class ApplyOp(object):
         self.C, self.M = C, out.M
         self.P = ops.reduce_rows(self.M, C)
         self.partial = torch.zeros(self.P, 3, C, device=g.dev)
+        self.pflat = self.partial.view(-1)
         for src, bn in ((self.m_src, self.m_bn), (self.o_src, self.o_bn)):
             if bn is not None and src.kind == 'act':        # BN over a materialised tensor: statistics by a separate pass
                 bn.stat_part = torch.zeros(self.P, 2, C, device=g.dev)
-        ps = g.ps
-        self.views = {}
-        for bn in (self.m_bn, self.o_bn):
-            if bn is not None:
-                self.views[bn] = (ps.view(bn.gamma), ps.view(bn.beta), ps.view(bn.gamma, ps.grad), ps.view(bn.beta, ps.grad))
 
     def _finalize_bn(self, src, bn):
-        ga, be, _, _ = self.views[bn]
-        mm, mv = (bn.moving_mean, bn.moving_var)
-        if not self.g.training:        # keras learning_phase False (run.py:21-24): normalise with the moving statistics
-            ops.bn_eval_scale_shift(ga, be, mm, mv, BN_EPSILON, bn.scale, bn.shift, self.C)
-            return
         if src.kind == 'conv':
-            st = src.stat_cell['t']
-            ops.bn_finalize(st[0], st[1], src.stat_rows, self.C, self.C, self.M, ga, be, BN_EPSILON, BN_MOMENTUM, mm, mv, bn.scale,
-                            bn.shift, bn.mean, bn.rstd)
+            psum, psq, P, rs = src.stats
         else:
-            ops.bn_stats(src.buf, self.M, self.C, bn.stat_part)
-            ops.bn_finalize(bn.stat_part, bn.stat_part[0, 1], self.P, 2 * self.C, self.C, self.M, ga, be, BN_EPSILON, BN_MOMENTUM, mm,
-                            mv, bn.scale, bn.shift, bn.mean, bn.rstd)
+            if self.g.training:
+                ops.bn_stats(src.buf, self.M, self.C, bn.stat_part)
+            flat = bn.stat_part.view(-1)
+            psum, psq, P, rs = flat, flat[self.C:], self.P, 2 * self.C
+        bn.fwd_finalize(psum, psq, P, rs, self.M, self.g.training)
 
     def forward(self):
         if self.m_bn is not None:
@@ -449,7 +551,6 @@ class ApplyOp(object):
         ops.bn_act_fwd(self.m_src.buf, sc, sh, self.out.buf, self.M, self.C, self.relu, **kw)
 
     def plan_backward(self):
-        # main branch gradient destination
         m = self.m_src
         if m.kind == 'conv':
             self.m_dst, self.m_acc = 'dy', False
@@ -465,38 +566,27 @@ class ApplyOp(object):
     def backward(self):
         out, m, o = self.out, self.m_src, self.o_src
         mb, ob = self.m_bn, self.o_bn
-        need_reduce = mb is not None or ob is not None
-        if need_reduce:
-            # the reduce kernel always needs a (y, mean, rstd) triple for quantity 1; use the main BN if present
+        if mb is not None or ob is not None:
+            # quantity 1 of the reduction belongs to the main BN if there is one, else to the shortcut BN
             y1, b1 = (m, mb) if mb is not None else (o, ob)
             y2, b2 = (o, ob) if (mb is not None and ob is not None) else (None, None)
             ops.bn_act_bwd_reduce(out.grad, out.buf, self.relu, y1.buf, b1.mean, b1.rstd, self.M, self.C, self.partial,
                                   y2=None if y2 is None else y2.buf, mean2=None if b2 is None else b2.mean,
                                   rstd2=None if b2 is None else b2.rstd)
-            _, _, dga, dbe = self.views[b1]
-            ops.bn_bwd_finalize(self.partial, self.P, self.C, 1, self.M, dga, dbe, b1.k1, b1.k2)
+            b1.bwd_finalize(self.pflat, self.P, self.C, 1, self.M)
             if b2 is not None:
-                _, _, dga2, dbe2 = self.views[b2]
-                ops.bn_bwd_finalize(self.partial, self.P, self.C, 2, self.M, dga2, dbe2, b2.k1, b2.k2)
+                b2.bwd_finalize(self.pflat, self.P, self.C, 2, self.M)
         kw = {}
         m_dst = m.dy if self.m_dst == 'dy' else m.grad
         if mb is not None:
-            kw.update(y=m.buf, a1=mb.scale_g(), mean=mb.mean, rstd=mb.rstd, k1=mb.k1, k2=mb.k2)
+            kw.update(y=m.buf, a1=mb.scale, mean=mb.mean, rstd=mb.rstd, k1=mb.k1, k2=mb.k2)       # gamma * rstd == forward scale
         kw.update(dy=m_dst, acc_dy=self.m_acc)
         if o is not None:
             if ob is not None:
-                kw.update(y2=o.buf, a2=ob.scale_g(), mean2=ob.mean, rstd2=ob.rstd, k1b=ob.k1, k2b=ob.k2, dy2=o.dy)
+                kw.update(y2=o.buf, a2=ob.scale, mean2=ob.mean, rstd2=ob.rstd, k1b=ob.k1, k2b=ob.k2, dy2=o.dy)
             else:
                 kw.update(dres=o.grad, acc_dres=self.o_acc)
         ops.bn_act_bwd_apply(out.grad, out.buf, self.relu, self.M, self.C, **kw)
-
-
-def _scale_g(self):
-    """gamma * rstd == the forward 'scale' vector"""
-    return self.scale
-
-
-BNState.scale_g = _scale_g
 
 
 class PoolOp(object):
@@ -517,19 +607,13 @@ class PoolOp(object):
         self.geom = (N, H, W, C, out.shape[1], out.shape[2], self.v.pt, self.v.pl)
         self.P = ops.reduce_rows(N * H * W, C)
         self.partial = torch.zeros(self.P, 3, C, device=g.dev)
-        if self.bn is not None:
-            ps = g.ps
-            self.views = (ps.view(self.bn.gamma), ps.view(self.bn.beta), ps.view(self.bn.gamma, ps.grad), ps.view(self.bn.beta, ps.grad))
 
     def forward(self):
         src, bn = self.src, self.bn
         N, H, W, C = src.shape
-        if bn is not None and not self.g.training:
-            ops.bn_eval_scale_shift(self.views[0], self.views[1], bn.moving_mean, bn.moving_var, BN_EPSILON, bn.scale, bn.shift, C)
-        elif bn is not None:
-            st = src.stat_cell['t']
-            ops.bn_finalize(st[0], st[1], src.stat_rows, C, C, N * H * W, self.views[0], self.views[1], BN_EPSILON, BN_MOMENTUM,
-                            bn.moving_mean, bn.moving_var, bn.scale, bn.shift, bn.mean, bn.rstd)
+        if bn is not None:
+            psum, psq, P, rs = src.stats
+            bn.fwd_finalize(psum, psq, P, rs, N * H * W, self.g.training)
         ops.bn_pool_fwd(src.buf, None if bn is None else bn.scale, None if bn is None else bn.shift, self.out.buf, self.argmax,
                         *self.geom, self.relu)
 
@@ -541,7 +625,7 @@ class PoolOp(object):
         N, H, W, C = src.shape
         if bn is not None:
             ops.bn_pool_bwd_reduce(out.grad, out.buf, self.argmax, self.relu, src.buf, bn.mean, bn.rstd, *self.geom, self.partial)
-            ops.bn_bwd_finalize(self.partial, self.P, C, 1, N * H * W, self.views[2], self.views[3], bn.k1, bn.k2)
+            bn.bwd_finalize(self.partial.view(-1), self.P, C, 1, N * H * W)
             ops.bn_pool_bwd_apply(out.grad, out.buf, self.argmax, self.relu, src.buf, bn.scale, bn.mean, bn.rstd, bn.k1, bn.k2, src.dy,
                                   *self.geom)
         else:

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import torch
 from . import _lib
-from ._lib import ConvProblem, LossConfig, check
+from ._lib import ConvProblem, LossConfig, MixProblem, check
 
 
 def _p(t):
@@ -96,8 +96,11 @@ def bn_act_bwd_reduce(dout, out, relu, y, mean, rstd, M, Cc, partial, y2=None, m
                                              M, Cc, _p(partial), _stream()), 'yolo_bn_act_bwd_reduce')
 
 
-def bn_bwd_finalize(partial, P, Cc, which, count, dgamma, dbeta, k1, k2):
-    check(_lib.load().yolo_bn_bwd_finalize(_p(partial), P, Cc, which, float(count), _p(dgamma), _p(dbeta), _p(k1), _p(k2), _stream()),
+def bn_bwd_finalize(partial, P, Cc, which, count, dgamma, dbeta, k1, k2, row_stride=None, q_stride=None):
+    """partial: [P][3][q_stride] (default q_stride = Cc); pass a tensor view offset to a channel sub-range for grouped BatchNorms"""
+    q = Cc if q_stride is None else q_stride
+    rs = 3 * q if row_stride is None else row_stride
+    check(_lib.load().yolo_bn_bwd_finalize(_p(partial), P, rs, q, Cc, which, float(count), _p(dgamma), _p(dbeta), _p(k1), _p(k2), _stream()),
           'yolo_bn_bwd_finalize')
 
 
@@ -121,6 +124,29 @@ def bn_pool_bwd_apply(dout, out, argmax, relu, y, a1, mean, rstd, k1, k2, dy, N,
 def upcat_split_bwd(dcat, da, acc_a, db, acc_b, N, H, W, C0, C1):
     check(_lib.load().yolo_upcat_split_bwd(_p(dcat), _p(da), int(acc_a), _p(db), int(acc_b), N, H, W, C0, C1, _stream()),
           'yolo_upcat_split_bwd')
+
+
+def mix_problem(N, H, W, Cc, split, ksize):
+    p = MixProblem(N, H, W, Cc)
+    for i, v in enumerate(split):
+        p.split[i] = int(v)
+    for i, v in enumerate(ksize):
+        p.ksize[i] = int(v)
+    return p
+
+
+def dwconv_mix_fwd(p, x, w, y):
+    check(_lib.load().yolo_dwconv_mix_fwd(C.byref(p), _p(x), _p(w[0]), _p(w[1]), _p(w[2]), _p(w[3]), _p(y), _stream()), 'yolo_dwconv_mix_fwd')
+
+
+def dwconv_mix_dgrad(p, dy, w, dx, accumulate=False):
+    check(_lib.load().yolo_dwconv_mix_dgrad(C.byref(p), _p(dy), _p(w[0]), _p(w[1]), _p(w[2]), _p(w[3]), _p(dx), int(accumulate), _stream()),
+          'yolo_dwconv_mix_dgrad')
+
+
+def dwconv_mix_wgrad(p, x, dy, dw):
+    check(_lib.load().yolo_dwconv_mix_wgrad(C.byref(p), _p(x), _p(dy), _p(dw[0]), _p(dw[1]), _p(dw[2]), _p(dw[3]), _stream()),
+          'yolo_dwconv_mix_wgrad')
 
 
 def reduce_partials(partial, P, row_stride, Cc, out):
