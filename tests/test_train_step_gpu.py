@@ -110,7 +110,11 @@ def test_forward_loss_grads_and_step(backbone, rect):
     from yolov3_tensorflow_amd import engine
     inject = []
     for op in model.g.tape:
-        if isinstance(op, (engine.ConvOp, engine.MixConvOp)):
+        if isinstance(op, engine.MixConvOp):          # the oracle runs the 4 depthwise convs of a block one by one
+            sp = list(op.y.mp.split)
+            full = op.y.buf.float().cpu()
+            inject.extend(full[..., sp[i]:sp[i + 1]].contiguous() for i in range(4))
+        elif isinstance(op, engine.ConvOp):
             if not op.y.f32:
                 inject.append(op.y.buf.float().cpu())
         else:
