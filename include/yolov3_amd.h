@@ -62,6 +62,10 @@ int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, const void* 
                       int split_k, void* stream);
 /* bf16 [Cout][R][S][Cin] -> bf16 [Cin][R][S][Cout] with flipped taps (operand layout of yolo_conv2d_dgrad). */
 int yolo_repack_dgrad_weights(const void* w_fwd, void* w_dgrad, int Cout, int R, int S, int Cin, void* stream);
+/* the same for every layer in ONE launch.  table_dev: device int32 [nlayers][8] = {src element offset into w_fwd_flat, dst element
+ * offset into w_dgrad_flat, Cout, R*S, Cin, first tile index, ceil(Cin/32), ceil(Cout/32)}; total_tiles = sum of R*S*tiles. */
+int yolo_repack_dgrad_weights_batched(const void* w_fwd_flat, void* w_dgrad_flat, const int32_t* table_dev, int nlayers, int total_tiles,
+                                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * BatchNorm (training mode) + ReLU + residual add, stem BN -> max-pool -> ReLU, and their backward passes.

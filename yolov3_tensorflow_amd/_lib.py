@@ -44,6 +44,7 @@ SIGNATURES = {
     'yolo_conv2d_dgrad': (I, [CP, P, P, P, I, P]),
     'yolo_conv2d_wgrad': (I, [CP, P, P, P, P, I, P]),
     'yolo_repack_dgrad_weights': (I, [P, P, I, I, I, I, P]),
+    'yolo_repack_dgrad_weights_batched': (I, [P, P, P, I, I, P]),
     'yolo_reduce_rows': (I, [I, I]),
     'yolo_bn_stats': (I, [P, I, I, P, P]),
     'yolo_bn_finalize': (I, [P, P, I, I64, I, F, P, P, F, F, P, P, P, P, P, P, P]),

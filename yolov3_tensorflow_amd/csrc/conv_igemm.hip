@@ -15,6 +15,7 @@
 //                    so fragments are read with ds_read_b64_tr_b16 (hardware transpose); split over pixel ranges,
 //                    fp32 atomics into dW.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -46,52 +47,90 @@ __device__ __forceinline__ RowInfo decode_row(const Gather& g, int m) {
   return r;
 }
 
-// One 16-byte k-chunk of one row; zero outside the image / outside K.
-__device__ __forceinline__ uint4 gather_chunk(const Gather& g, const RowInfo& r, int tap_r, int tap_s, int c, bool kvalid) {
+// XOR-swizzled [rows][64 bf16] image: 128-byte rows, 16-byte chunk index ^= row & 7.
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// 16 bytes of zeros in global memory: the source of every out-of-image / out-of-K chunk of the LDS-DMA gathers
+__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// address of one 16-byte k-chunk of one row, or the zero chunk
+__device__ __forceinline__ const bf16_t* gather_addr(const Gather& g, const RowInfo& r, int tap_r, int tap_s, int c, bool kvalid) {
   int hn = r.hb + tap_r, wn = r.wb + tap_s;
   bool ok = kvalid & (hn >= 0) & (wn >= 0);
   if (g.den == 2) { ok = ok & (((hn | wn) & 1) == 0); hn >>= 1; wn >>= 1; }
   ok = ok & (hn < g.Hs) & (wn < g.Ws);
-  uint4 v = make_uint4(0, 0, 0, 0);
+  const bf16_t* p = reinterpret_cast<const bf16_t*>(&g_zero16);
   if (ok) {
-    const bf16_t* p;
     if (c < g.C0) p = g.src0 + ((size_t)(r.n * (g.Hs >> 1) + (hn >> 1)) * (g.Ws >> 1) + (wn >> 1)) * g.C0 + c;
     else          p = g.src1 + ((size_t)(r.n * g.Hs + hn) * g.Ws + wn) * g.C1 + (c - g.C0);
-    v = *reinterpret_cast<const uint4*>(p);
   }
-  return v;
+  return p;
 }
 
-// XOR-swizzled [rows][64 bf16] image: 128-byte rows, 16-byte chunk index ^= row & 7.
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// XCD-aware tile order (MI355X deals consecutive workgroups round-robin over its 8 XCDs, each with a private L2): give every XCD a
+// contiguous run of tiles so that the tiles sharing a pixel panel / weight panel hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
 
-constexpr int BM = 128;  // pixels per workgroup tile
-constexpr int BK = 64;   // K elements per stage
+constexpr int BK = 64;  // K elements per stage
 
-template <int BN, bool OUT_F32>
+// Forward / data-gradient implicit GEMM.  BM pixels x BN channels per 256-thread workgroup; a 3-stage LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: 16 B per lane, no VGPR staging), counted vmcnt so that one stage stays in flight across the single raw
+// s_barrier of each K-step; the XOR swizzle of the LDS image is applied on the SOURCE address (LDS-DMA writes lane-linear).
+// FAST gather (den == 1, single source, <= 32 taps): address = row base + tap offset, validity = one bit of a per-row tap mask, both
+// computed once per tile; the generic path (stride-2 data gradient, fused upsample+concat) recomputes coordinates per K-step.
+template <int BM, int BN, bool OUT_F32, bool FAST>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* __restrict__ Wt, const float* __restrict__ bias,
                                                         void* __restrict__ Yv, int ldy, int accumulate,
                                                         float* __restrict__ stat_sum, float* __restrict__ stat_sq,
                                                         int Kout, int tiles_n) {
-  constexpr int WM = (BN == 128) ? 2 : 4;  // waves along pixels
-  constexpr int WN = 4 / WM;               // waves along channels
+  constexpr int NSTAGE = 2;                // 2 x (A + B) = 64 KB for 128 x 128: two workgroups per CU overlap each other's address math
+  constexpr int WN = (BN == 128) ? 2 : 1;  // waves along channels
+  constexpr int WM = 4 / WN;               // waves along pixels
   constexpr int PT = BM / WM / 16;         // 16-pixel MFMA tiles per wave
   constexpr int CT = BN / WN / 16;         // 16-channel MFMA tiles per wave (= 4)
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int B_BYTES = BN * BK * 2;
-  constexpr int B_ROWS_PER_THREAD = BN / 32;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 32;         // LDS-DMA instructions per wave per stage (8 rows x 128 B each)
+  constexpr int B_INSTR = BN / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int ccol = tid & 7;   // k-chunk column of this thread inside a stage
-  const int rbase = tid >> 3; // first row handled (then +32 per i)
-  RowInfo rows[4];
+  // LDS-DMA lane geometry: lane -> row (lane >> 3) of the instruction's 8 rows, LDS slot (lane & 7); the slot holds global chunk
+  // slot ^ (row & 7) (row & 7 == lane >> 3 because instruction row blocks are 8-aligned)
+  const int lrow = lane >> 3;
+  const int cchunk = (lane & 7) ^ lrow;
+  RowInfo rows[A_INSTR];
+  int rbase[A_INSTR];
+  unsigned vmask[A_INSTR];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) rows[i] = decode_row(g, m0 + rbase + 32 * i);
+  for (int j = 0; j < A_INSTR; ++j) {
+    rows[j] = decode_row(g, m0 + (wave * A_INSTR + j) * 8 + lrow);
+    if constexpr (FAST) {
+      rbase[j] = ((rows[j].n * g.Hs + rows[j].hb) * g.Ws + rows[j].wb) * g.C1;
+      unsigned mk = 0;
+      for (int t = 0; t < g.RS; ++t) {
+        const int tr = t / g.S, ts = t - tr * g.S;
+        const int hn = rows[j].hb + tr, wn = rows[j].wb + ts;
+        mk |= ((hn >= 0) & (hn < g.Hs) & (wn >= 0) & (wn < g.Ws)) ? (1u << t) : 0u;
+      }
+      vmask[j] = mk;
+    }
+  }
+  const bf16_t* wrow[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) wrow[j] = Wt + (size_t)(n0 + (wave * B_INSTR + j) * 8 + lrow) * g.Kg + cchunk * 8;
 
   f32x4_t acc[CT][PT];
 #pragma unroll
@@ -101,34 +140,35 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
 
   const int nk = (g.Kg + BK - 1) / BK;
   const int cmask = (1 << g.lgC8) - 1;
-  uint4 ra[4], rb[B_ROWS_PER_THREAD];
 
-  auto load_stage = [&](int kt) {
-    int q = kt * (BK / 8) + ccol;
-    int tap = q >> g.lgC8;
-    int c = (q & cmask) << 3;
-    bool kvalid = tap < g.RS;
-    int tr = tap / g.S, ts = tap - tr * g.S;
+  auto issue_stage = [&](int kt, int buf) {
+    char* sA = smem + buf * STAGE + wave * (A_INSTR * 1024);
+    char* sB = smem + buf * STAGE + A_BYTES + wave * (B_INSTR * 1024);
+    const int q = kt * (BK / 8) + cchunk;
+    const int tap = q >> g.lgC8;
+    const int c = (q & cmask) << 3;
+    const bool kvalid = tap < g.RS;
+    const int tr = tap / g.S, ts = tap - tr * g.S;
+    if constexpr (FAST) {
+      const int toff = (tr * g.Ws + ts) * g.C1 + c;
+      const unsigned tbit = kvalid ? (1u << tap) : 0u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = gather_chunk(g, rows[i], tr, ts, c, kvalid);
-    int k = kt * BK + ccol * 8;
-    bool kv = k < g.Kg;
+      for (int j = 0; j < A_INSTR; ++j) {
+        const bf16_t* p = (vmask[j] & tbit) ? g.src1 + (rbase[j] + toff) : reinterpret_cast<const bf16_t*>(&g_zero16);
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(sA + j * 1024), 16, 0, 0);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (kv) rb[i] = *reinterpret_cast<const uint4*>(Wt + (size_t)(n0 + rbase + 32 * i) * g.Kg + k);
+      for (int j = 0; j < A_INSTR; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)gather_addr(g, rows[j], tr, ts, c, kvalid), (lptr_t)(sA + j * 1024), 16, 0, 0);
     }
-  };
-  auto store_stage = [&](int buf) {
-    char* sA = smem + buf * (A_BYTES + B_BYTES);
-    char* sB = sA + A_BYTES;
+    const bool kv = kt * BK + cchunk * 8 < g.Kg;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sA + swz(rbase + 32 * i, ccol)) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_ROWS_PER_THREAD; ++i) *reinterpret_cast<uint4*>(sB + swz(rbase + 32 * i, ccol)) = rb[i];
+    for (int j = 0; j < B_INSTR; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(kv ? wrow[j] + kt * BK : reinterpret_cast<const bf16_t*>(&g_zero16)), (lptr_t)(sB + j * 1024), 16, 0, 0);
   };
   auto compute_stage = [&](int buf) {
-    const char* sA = smem + buf * (A_BYTES + B_BYTES);
+    const char* sA = smem + buf * STAGE;
     const char* sB = sA + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -145,14 +185,13 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
     }
   };
 
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
+  issue_stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_stage(kt + 1);
-    compute_stage(kt & 1);
-    if (kt + 1 < nk) store_stage((kt + 1) & 1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of stage kt has landed
+    __builtin_amdgcn_s_barrier();                       // ... every wave's has; and every wave has finished reading stage kt-1
+    asm volatile("" ::: "memory");
+    if (kt + 1 < nk) issue_stage(kt + 1, (kt + 1) % NSTAGE);   // in flight during the MFMAs below
+    compute_stage(kt % NSTAGE);
   }
 
   // ---- epilogue: lane holds channels co..co+3 (rows of D) of pixel (column of D) ----
@@ -222,70 +261,93 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
 // ------------------------------------------------------------------------------------------------------------------
 // wgrad: D[co][kcol] = sum_p dY[p][co] * X[p][kcol]
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int WG_BCO = 128;   // rows of D per workgroup (output channels)
 constexpr int WG_BKC = 128;   // columns of D per workgroup (k-columns = (tap, ci))
 constexpr int WG_BP = 64;     // pixels per stage (2 MFMA k-steps)
-constexpr int WG_LD = 272;    // LDS row stride in bytes: 256 + 16 pad, 16-byte aligned
+
+// LDS image [64 pixels][128 columns] bf16 with plain 256-byte rows and the 16-byte chunk index XOR-ed with
+// f(row) = ((row & 3) << 2) | ((row >> 2) & 3): filled lane-linearly by LDS-DMA (swizzle applied on the source side) and read
+// transposed with ds_read_b64_tr_b16 without bank conflicts (cdna guide T10, image (b)).
+__device__ __forceinline__ int wg_f(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 __device__ __forceinline__ bf16x8_t tr_frag(const char* img, int p0, int col0, int lane) {
   // lane l (g = l>>4, i = l&15) receives image[p0 + 8g + j][col0 + i], j = 0..7 (two 4x16 transposed block reads)
   const int gq = lane >> 4, i = lane & 15;
-  const char* a = img + (p0 + 8 * gq + (i >> 2)) * WG_LD + (col0 + 4 * (i & 3)) * 2;
+  const int r0 = p0 + 8 * gq + (i >> 2), r1 = r0 + 4;
+  const int ch = (col0 >> 3) + ((i & 3) >> 1), hb = (i & 1) << 3;
   typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
-  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(a));
-  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(a + 4 * WG_LD));
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(img + r0 * 256 + ((ch ^ wg_f(r0)) << 4) + hb));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(img + r1 * 256 + ((ch ^ wg_f(r1)) << 4) + hb));
   typedef short s16x8_t __attribute__((ext_vector_type(8)));
   s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
+// m -> (n, ho, wo) with float reciprocals + one correction step (exact for m < 2^24; the launcher checks M)
+__device__ __forceinline__ void fast_divmod(int m, int d, float rd, int& q, int& r) {
+  q = (int)((float)m * rd);
+  r = m - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+}
+
+template <int BCO>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(Gather g, const bf16_t* __restrict__ dY, int ldy,
-                                                          float* __restrict__ dW, int Kout, int steps_per_split) {
-  constexpr int IMG = WG_BP * WG_LD;  // bytes of one [64 pix][128 col] image
+                                                          float* __restrict__ dW, int Kout, int steps_per_split, float rhw, float rw) {
+  constexpr int IMG = WG_BP * 256;          // bytes of one [64 pix][128 col] image
+  constexpr int COT = BCO / 32;             // 16-row co tiles per wave (waves: 2 along co x 2 along kcol)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;  // wave tile: co [wr*64, +64) x kcol [wc*64, +64)
-  const int kc0 = blockIdx.x * WG_BKC, co0 = blockIdx.y * WG_BCO;
+  const int wr = wave >> 1, wc = wave & 1;  // wave tile: co [wr*BCO/2, +BCO/2) x kcol [wc*64, +64)
+  const int kc0 = blockIdx.x * WG_BKC, co0 = blockIdx.y * BCO;
   const int nsteps = (g.M + WG_BP - 1) / WG_BP;
   const int s_begin = blockIdx.z * steps_per_split;
   const int s_end = min(nsteps, s_begin + steps_per_split);
   if (s_begin >= s_end) return;
 
-  const int ccol = tid & 15;  // 16-byte chunk column (of 16) in both images
-  const int rbase = tid >> 4; // pixel row (then +16 per i)
-  // this thread's fixed k-chunk of the X gather
-  const int q = (kc0 >> 3) + ccol;
-  const int tap = q >> g.lgC8;
-  const int xc = (q & ((1 << g.lgC8) - 1)) << 3;
-  const bool kvalid = tap < g.RS;
-  const int tr = tap / g.S, ts = tap - tr * g.S;
-  const int yc = co0 + ccol * 8;
-  const bool yvalid = yc < Kout;
-
-  f32x4_t acc[4][4];
+  // LDS-DMA geometry: instruction j of this wave covers image rows (wave*4 + j)*4 .. +3; lane -> row +(lane >> 4), slot lane & 15,
+  // which holds chunk slot ^ f(row) with f(row) = ((lane >> 4) << 2) | j
+  const int lr = lane >> 4, slot = lane & 15;
+  int x_tr[4], x_ts[4], x_c[4], y_c[4];
+  bool x_kv[4], y_cv[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int j = 0; j < 4; ++j) {
+    const int ch = slot ^ ((lr << 2) | j);
+    const int q = (kc0 >> 3) + ch;
+    const int tap = q >> g.lgC8;
+    x_c[j] = (q & ((1 << g.lgC8) - 1)) << 3;
+    x_kv[j] = tap < g.RS;
+    x_tr[j] = tap / g.S;
+    x_ts[j] = tap - x_tr[j] * g.S;
+    y_c[j] = co0 + ch * 8;
+    y_cv[j] = (BCO == 128 || ch < 8) && y_c[j] < Kout;
+  }
+  const int hw = g.Ho * g.Wo;
+
+  f32x4_t acc[COT][4];
+#pragma unroll
+  for (int a = 0; a < COT; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  uint4 rx[4], ry[4];
-  auto load_stage = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = st * WG_BP + rbase + 16 * i;
-      RowInfo r = decode_row(g, m);
-      rx[i] = gather_chunk(g, r, tr, ts, xc, kvalid);
-      ry[i] = make_uint4(0, 0, 0, 0);
-      if (yvalid && m < g.M) ry[i] = *reinterpret_cast<const uint4*>(dY + (size_t)m * ldy + yc);
-    }
-  };
-  auto store_stage = [&](int buf) {
-    char* sX = smem + buf * 2 * IMG;
+  auto issue_stage = [&](int st, int buf) {
+    char* sX = smem + buf * 2 * IMG + wave * 4096;
     char* sY = sX + IMG;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(sX + (rbase + 16 * i) * WG_LD + ccol * 16) = rx[i];
-      *reinterpret_cast<uint4*>(sY + (rbase + 16 * i) * WG_LD + ccol * 16) = ry[i];
+    for (int j = 0; j < 4; ++j) {
+      const int m = st * WG_BP + (wave * 4 + j) * 4 + lr;
+      const bf16_t* px = reinterpret_cast<const bf16_t*>(&g_zero16);
+      const bf16_t* py = px;
+      if (m < g.M) {
+        int n, rem, ho, wo;
+        fast_divmod(m, hw, rhw, n, rem);
+        fast_divmod(rem, g.Wo, rw, ho, wo);
+        RowInfo r;
+        r.n = n; r.hb = ho * g.smul - g.pad_h; r.wb = wo * g.smul - g.pad_w;
+        px = gather_addr(g, r, x_tr[j], x_ts[j], x_c[j], x_kv[j]);
+        if (y_cv[j]) py = dY + (size_t)m * ldy + y_c[j];
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(sX + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)py, (lptr_t)(sY + j * 1024), 16, 0, 0);
     }
   };
   auto compute_stage = [&](int buf) {
@@ -293,39 +355,38 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(Gather g, const bf16_t
     const char* sY = sX + IMG;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t yf[4], xf[4];
+      bf16x8_t yf[COT], xf[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) yf[a] = tr_frag(sY, ks * 32, wr * 64 + a * 16, lane);
+      for (int a = 0; a < COT; ++a) yf[a] = tr_frag(sY, ks * 32, wr * (BCO / 2) + a * 16, lane);
 #pragma unroll
       for (int b = 0; b < 4; ++b) xf[b] = tr_frag(sX, ks * 32, wc * 64 + b * 16, lane);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < COT; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
     }
   };
 
-  load_stage(s_begin);
-  store_stage(0);
-  __syncthreads();
+  issue_stage(s_begin, 0);
   for (int st = s_begin; st < s_end; ++st) {
     const int buf = (st - s_begin) & 1;
-    if (st + 1 < s_end) load_stage(st + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (st + 1 < s_end) issue_stage(st + 1, buf ^ 1);
     compute_stage(buf);
-    if (st + 1 < s_end) store_stage(buf ^ 1);
-    __syncthreads();
   }
 
   // D[row = co][col = kcol]: lane holds rows 4*(lane>>4)+j, column lane&15
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < COT; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int kc = kc0 + wc * 64 + b * 16 + (lane & 15);
       if (kc < g.Kg) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int co = co0 + wr * 64 + a * 16 + (lane >> 4) * 4 + j;
+          const int co = co0 + wr * (BCO / 2) + a * 16 + (lane >> 4) * 4 + j;
           if (co < Kout) atomicAdd(dW + (size_t)co * g.Kg + kc, acc[a][b][j]);
         }
       }
@@ -345,6 +406,31 @@ __global__ void repack_dgrad_kernel(const bf16_t* __restrict__ wf, bf16_t* __res
   for (int r = threadIdx.y; r < 32; r += 8) {
     int ci = ci0 + r, co = co0 + threadIdx.x;
     if (ci < Cin && co < Cout) wd[((size_t)ci * RS + (RS - 1 - tap)) * Cout + co] = tile[threadIdx.x][r];
+  }
+}
+
+// all layers in one launch: table[l] = {src_off, dst_off, Cout, RS, Cin, tile_begin, tiles_ci, tiles_co} (element offsets into the flat
+// bf16 buffers); tile order inside a layer: tap-major, then co tile, then ci tile
+__global__ void repack_dgrad_batched_kernel(const bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, const int* __restrict__ table, int nlayers) {
+  __shared__ bf16_t tile[32][33];
+  int l = 0;
+  while (l + 1 < nlayers && (int)blockIdx.x >= table[(l + 1) * 8 + 5]) ++l;
+  const int* t = table + l * 8;
+  const int Cout = t[2], RS = t[3], Cin = t[4], tci = t[6], tco = t[7];
+  int id = blockIdx.x - t[5];
+  const int tap = id / (tci * tco);
+  id -= tap * tci * tco;
+  const int co0 = (id / tci) * 32, ci0 = (id % tci) * 32;
+  const bf16_t* src = wf + t[0];
+  bf16_t* dst = wd + t[1];
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + threadIdx.x;
+    tile[r][threadIdx.x] = (co < Cout && ci < Cin) ? src[((size_t)co * RS + tap) * Cin + ci] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + threadIdx.x;
+    if (ci < Cin && co < Cout) dst[((size_t)ci * RS + (RS - 1 - tap)) * Cout + co] = tile[threadIdx.x][r];
   }
 }
 
@@ -382,31 +468,64 @@ Gather fwd_gather(const yolo_conv_problem* p, const void* src0, const void* src1
   return g;
 }
 
+// tile choice: 128 x 128 for wide layers, 128 x 64 for 64-channel outputs; 64-pixel tiles when 128-pixel tiles would leave
+// most of the 256 CUs idle (the 13x13 / 26x26 layers at batch 32)
+struct TileCfg { int bm, bn; };
+TileCfg pick_tile(int M, int Kout) {
+  TileCfg t;
+  t.bn = (Kout % 128 == 0) ? 128 : 64;
+  const long tiles128 = (long)((M + 127) / 128) * (Kout / t.bn);
+  t.bm = tiles128 < 512 ? 64 : 128;
+  return t;
+}
+int stat_rows_for(int M, int Kout) {
+  const TileCfg t = pick_tile(M, Kout);
+  const int wm = (t.bn == 128) ? 2 : 4;
+  return ((M + t.bm - 1) / t.bm) * wm;
+}
+
+template <int BM, int BN, bool F32, bool FAST>
+int launch_tile2(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
+                hipStream_t st) {
+  const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
+  constexpr size_t lds = 2 * (BM * BK * 2 + BN * BK * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, F32, FAST>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, F32, FAST>), dim3(tiles_m * tn), dim3(256), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
+                     ssum, ssq, Kout, tn);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+template <int BM, int BN, bool F32>
+int launch_tile(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
+                hipStream_t st) {
+  const bool fast = g.den == 1 && g.C0 == 0 && g.RS <= 32 &&
+                    (size_t)g.Hs * g.Ws * g.C1 * (size_t)(g.M / (g.Ho * g.Wo) + 1) < (1ull << 31);
+  if (fast) return launch_tile2<BM, BN, F32, true>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+  return launch_tile2<BM, BN, F32, false>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+}
+
 template <bool F32>
 int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq,
                int Kout, hipStream_t st) {
-  const int tiles_m = (g.M + BM - 1) / BM;
-  if (Kout % 128 == 0) {
-    const int tn = Kout / 128;
-    const size_t lds = 2 * (BM * BK * 2 + 128 * BK * 2);
-    hipLaunchKernelGGL((igemm_fwd_kernel<128, F32>), dim3(tiles_m * tn), dim3(256), lds, st, g, (const bf16_t*)w, bias, y, ldy,
-                       accumulate, ssum, ssq, Kout, tn);
-  } else {
-    const int tn = Kout / 64;
-    const size_t lds = 2 * (BM * BK * 2 + 64 * BK * 2);
-    hipLaunchKernelGGL((igemm_fwd_kernel<64, F32>), dim3(tiles_m * tn), dim3(256), lds, st, g, (const bf16_t*)w, bias, y, ldy,
-                       accumulate, ssum, ssq, Kout, tn);
-  }
-  YOLO_LAUNCH_CHECK();
-  return YOLO_OK;
+  const TileCfg t = pick_tile(g.M, Kout);
+  if (t.bm == 128 && t.bn == 128) return launch_tile<128, 128, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+  if (t.bm == 128 && t.bn == 64) return launch_tile<128, 64, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+  if (t.bm == 64 && t.bn == 128) return launch_tile<64, 128, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+  return launch_tile<64, 64, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
 }
 
 }  // namespace
 
 extern "C" int yolo_conv2d_stat_rows(const yolo_conv_problem* p) {
-  if (!p || p->Cout % 64 != 0) return YOLO_ERR_INVALID_ARG;
-  const int tiles_m = (p->N * p->Ho * p->Wo + BM - 1) / BM;
-  return tiles_m * ((p->Cout % 128 == 0) ? 2 : 4);
+  if (!p || p->Cout % 64 != 0 || p->N <= 0 || p->Ho <= 0 || p->Wo <= 0) return YOLO_ERR_INVALID_ARG;
+  return stat_rows_for(p->N * p->Ho * p->Wo, p->Cout);
 }
 
 extern "C" int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd,
@@ -447,11 +566,15 @@ extern "C" int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, c
   YOLO_CHECK_ARG(src1 && dy && dw, "null pointer");
   YOLO_CHECK_ARG(p->C0 == 0 || src0, "C0 > 0 needs src0");
   Gather g = fwd_gather(p, src0, src1);
+  YOLO_CHECK_ARG(g.M < (1 << 24), "wgrad row decode needs N*Ho*Wo < 2^24");
+  const int bco = (p->Cout % 128 == 0) ? 128 : 64;
   const int tiles_k = (g.Kg + WG_BKC - 1) / WG_BKC;
-  const int tiles_c = (p->Cout + WG_BCO - 1) / WG_BCO;
+  const int tiles_c = (p->Cout + bco - 1) / bco;
   const int nsteps = (g.M + WG_BP - 1) / WG_BP;
   if (split_k <= 0) {  // aim at ~3 workgroups per CU, at least 8 pixel-steps per workgroup
-    split_k = (768 + tiles_k * tiles_c - 1) / (tiles_k * tiles_c);
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("YOLO_WGRAD_BLOCKS"); target = e ? atoi(e) : 768; }
+    split_k = (target + tiles_k * tiles_c - 1) / (tiles_k * tiles_c);
     const int max_split = (nsteps + 7) / 8;
     if (split_k > max_split) split_k = max_split;
     if (split_k < 1) split_k = 1;
@@ -460,9 +583,14 @@ extern "C" int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, c
   const int sps = (nsteps + split_k - 1) / split_k;
   split_k = (nsteps + sps - 1) / sps;
   YOLO_CHECK_ARG(split_k <= 65535, "split_k too large");
-  const size_t lds = 2 * 2 * WG_BP * WG_LD;
-  hipLaunchKernelGGL(igemm_wgrad_kernel, dim3(tiles_k, tiles_c, split_k), dim3(256), lds, (hipStream_t)stream, g,
-                     (const bf16_t*)dy, p->Cout, dw, p->Cout, sps);
+  const size_t lds = 2 * 2 * WG_BP * 256;
+  const float rhw = 1.0f / (float)(p->Ho * p->Wo), rw = 1.0f / (float)p->Wo;
+  if (bco == 128)
+    hipLaunchKernelGGL(igemm_wgrad_kernel<128>, dim3(tiles_k, tiles_c, split_k), dim3(256), lds, (hipStream_t)stream, g, (const bf16_t*)dy,
+                       p->Cout, dw, p->Cout, sps, rhw, rw);
+  else
+    hipLaunchKernelGGL(igemm_wgrad_kernel<64>, dim3(tiles_k, tiles_c, split_k), dim3(256), lds, (hipStream_t)stream, g, (const bf16_t*)dy,
+                       p->Cout, dw, p->Cout, sps, rhw, rw);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
@@ -471,6 +599,15 @@ extern "C" int yolo_repack_dgrad_weights(const void* w_fwd, void* w_dgrad, int C
   YOLO_CHECK_ARG(w_fwd && w_dgrad && Cout > 0 && Cin > 0 && R > 0 && S > 0, "bad argument");
   hipLaunchKernelGGL(repack_dgrad_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, R * S), dim3(32, 8), 0, (hipStream_t)stream,
                      (const bf16_t*)w_fwd, (bf16_t*)w_dgrad, Cout, R * S, Cin);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_repack_dgrad_weights_batched(const void* w_fwd_flat, void* w_dgrad_flat, const int32_t* table_dev, int nlayers,
+                                                 int total_tiles, void* stream) {
+  YOLO_CHECK_ARG(w_fwd_flat && w_dgrad_flat && table_dev && nlayers > 0 && total_tiles > 0, "bad argument");
+  hipLaunchKernelGGL(repack_dgrad_batched_kernel, dim3(total_tiles), dim3(32, 8), 0, (hipStream_t)stream, (const bf16_t*)w_fwd_flat,
+                     (bf16_t*)w_dgrad_flat, (const int*)table_dev, nlayers);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

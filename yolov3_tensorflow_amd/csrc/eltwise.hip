@@ -63,10 +63,27 @@ __device__ __forceinline__ bool column_reduce(const float* const (&src)[K], int 
 #pragma unroll
   for (int k = 0; k < K; ++k) s[k] = 0.0;
   if (c < C) {
-    for (int p = rl; p < P; p += 128) {
+    // 4 independent float partial sums per quantity keep 4*K loads in flight (the loop is load-latency bound); each float sum
+    // covers <= P/512 rows before it is widened
+    float f[K][4];
 #pragma unroll
-      for (int k = 0; k < K; ++k) s[k] += (double)src[k][(size_t)p * rstride + c];
+    for (int k = 0; k < K; ++k) f[k][0] = f[k][1] = f[k][2] = f[k][3] = 0.f;
+    int p = rl;
+    for (; p + 384 < P; p += 512) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        f[k][0] += src[k][(size_t)p * rstride + c];
+        f[k][1] += src[k][(size_t)(p + 128) * rstride + c];
+        f[k][2] += src[k][(size_t)(p + 256) * rstride + c];
+        f[k][3] += src[k][(size_t)(p + 384) * rstride + c];
+      }
     }
+    for (; p < P; p += 128) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) f[k][0] += src[k][(size_t)p * rstride + c];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = ((double)f[k][0] + (double)f[k][1]) + ((double)f[k][2] + (double)f[k][3]);
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) red[k][rl][cl] = s[k];

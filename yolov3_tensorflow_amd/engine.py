@@ -174,6 +174,7 @@ class Graph(object):
         self.fwd, self.bwd = [], []
         self.training = True
         self._alloc = []
+        self._repack_table = None
 
     # ------------------------------------------------------------------------------------------------ allocation helpers
     def _buffer(self, shape, dtype=torch.bfloat16):
@@ -366,9 +367,19 @@ class Graph(object):
             self.bwd.append(op.backward)
 
     def refresh_dgrad_weights(self):
-        for op in self.tape:
-            if isinstance(op, ConvOp) and op.needs_dgrad():
-                op.repack()
+        """flipped/transposed bf16 weight copies for the data-gradient pass, all layers in one launch"""
+        if self._repack_table is None:
+            rows, tiles = [], 0
+            for op in self.tape:
+                if isinstance(op, ConvOp) and op.needs_dgrad():
+                    co, k, _, ci = op.y.wp.dev_shape
+                    tci, tco = (ci + 31) // 32, (co + 31) // 32
+                    rows.append([op.y.wp.offset, op.dg_off, co, k * k, ci, tiles, tci, tco])
+                    tiles += k * k * tci * tco
+            self._repack_table = (torch.tensor(rows, dtype=torch.int32, device=self.dev), len(rows), tiles)
+        tab, n, tiles = self._repack_table
+        if n:
+            ops.repack_dgrad_weights_batched(self.ps.bf16, self.w_dgrad, tab, n, tiles)
 
     def run_forward(self):
         for f in self.fwd:

@@ -64,6 +64,11 @@ def repack_dgrad_weights(w_fwd, w_dgrad, Cout, R, S, Cin):
     check(_lib.load().yolo_repack_dgrad_weights(_p(w_fwd), _p(w_dgrad), Cout, R, S, Cin, _stream()), 'yolo_repack_dgrad_weights')
 
 
+def repack_dgrad_weights_batched(w_fwd_flat, w_dgrad_flat, table_dev, nlayers, total_tiles):
+    check(_lib.load().yolo_repack_dgrad_weights_batched(_p(w_fwd_flat), _p(w_dgrad_flat), _p(table_dev), nlayers, total_tiles, _stream()),
+          'yolo_repack_dgrad_weights_batched')
+
+
 def reduce_rows(M, Cc):
     r = _lib.load().yolo_reduce_rows(M, Cc)
     if r < 0:
