@@ -101,9 +101,10 @@ int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu, const voi
                           const float* mean2, const float* rstd2, const float* k1b, const float* k2b, void* dy2, void* dres,
                           int acc_dres, int64_t M, int C, void* stream);
 /* the same two passes through the stem's max-pool (rows = pre-pool pixels N*H*W) */
+/* (with relu and non-NULL gamma/beta the sums are taken over the pooled map: xhat = (out - beta) / gamma, y/argmax are not read) */
 int yolo_bn_pool_bwd_reduce(const void* dout, const void* out, const uint8_t* argmax, int relu, const void* y, const float* mean,
-                            const float* rstd, int N, int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l, float* partial,
-                            void* stream);
+                            const float* rstd, const float* gamma, const float* beta, int N, int H, int W, int C, int Ho, int Wo,
+                            int pad_t, int pad_l, float* partial, void* stream);
 int yolo_bn_pool_bwd_apply(const void* dout, const void* out, const uint8_t* argmax, int relu, const void* y, const float* a1,
                            const float* mean, const float* rstd, const float* k1, const float* k2, void* dy, int N, int H, int W, int C,
                            int Ho, int Wo, int pad_t, int pad_l, void* stream);

@@ -53,7 +53,7 @@ SIGNATURES = {
     'yolo_bn_act_bwd_reduce': (I, [P, P, I, P, P, P, P, P, P, I, I, P, P]),
     'yolo_bn_bwd_finalize': (I, [P, I, I64, I64, I, I, F, P, P, P, P, P]),
     'yolo_bn_act_bwd_apply': (I, [P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, I64, I, P]),
-    'yolo_bn_pool_bwd_reduce': (I, [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    'yolo_bn_pool_bwd_reduce': (I, [P, P, P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, P]),
     'yolo_bn_pool_bwd_apply': (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     'yolo_upcat_split_bwd': (I, [P, P, I, P, I, I, I, I, I, I, P]),
     'yolo_pack_input': (I, [P, P, I64, I, P]),

@@ -240,8 +240,9 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
       }
     }
   }
-  if (stat_sum) {
-    const int prow = tile_m * WM + wm;
+  if (stat_sum) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
+    __syncthreads();                                  // every wave is done with the operand ring
+    float* red = reinterpret_cast<float*>(smem);      // [2][WM][BN]
 #pragma unroll
     for (int a = 0; a < CT; ++a)
 #pragma unroll
@@ -250,11 +251,19 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
         if ((lane & 15) == 0) {
-          const int co = n0 + wn * (CT * 16) + a * 16 + cq + j;
-          stat_sum[(size_t)prow * Kout + co] = s;
-          stat_sq[(size_t)prow * Kout + co] = q;
+          const int cl = wn * (CT * 16) + a * 16 + cq + j;
+          red[wm * BN + cl] = s;
+          red[(WM + wm) * BN + cl] = q;
         }
       }
+    __syncthreads();
+    for (int cl = tid; cl < BN; cl += 256) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { s += red[w * BN + cl]; q += red[(WM + w) * BN + cl]; }
+      stat_sum[(size_t)tile_m * Kout + n0 + cl] = s;
+      stat_sq[(size_t)tile_m * Kout + n0 + cl] = q;
+    }
   }
 }
 
@@ -480,8 +489,7 @@ TileCfg pick_tile(int M, int Kout) {
 }
 int stat_rows_for(int M, int Kout) {
   const TileCfg t = pick_tile(M, Kout);
-  const int wm = (t.bn == 128) ? 2 : 4;
-  return ((M + t.bm - 1) / t.bm) * wm;
+  return (M + t.bm - 1) / t.bm;      // one partial row per pixel tile
 }
 
 template <int BM, int BN, bool F32, bool FAST>

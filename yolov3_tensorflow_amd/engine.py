@@ -635,7 +635,8 @@ class PoolOp(object):
         src, bn, out = self.src, self.bn, self.out
         N, H, W, C = src.shape
         if bn is not None:
-            ops.bn_pool_bwd_reduce(out.grad, out.buf, self.argmax, self.relu, src.buf, bn.mean, bn.rstd, *self.geom, self.partial)
+            ops.bn_pool_bwd_reduce(out.grad, out.buf, self.argmax, self.relu, src.buf, bn.mean, bn.rstd, *self.geom, self.partial,
+                                   gamma=getattr(bn, 'v_gamma', None), beta=getattr(bn, 'v_beta', None))
             bn.bwd_finalize(self.partial.view(-1), self.P, C, 1, N * H * W)
             ops.bn_pool_bwd_apply(out.grad, out.buf, self.argmax, self.relu, src.buf, bn.scale, bn.mean, bn.rstd, bn.k1, bn.k2, src.dy,
                                   *self.geom)

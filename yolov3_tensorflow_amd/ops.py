@@ -116,9 +116,9 @@ def bn_act_bwd_apply(dout, out, relu, M, Cc, y=None, a1=None, mean=None, rstd=No
                                             int(acc_dres), M, Cc, _stream()), 'yolo_bn_act_bwd_apply')
 
 
-def bn_pool_bwd_reduce(dout, out, argmax, relu, y, mean, rstd, N, H, W, Cc, Ho, Wo, pt, pl, partial):
-    check(_lib.load().yolo_bn_pool_bwd_reduce(_p(dout), _p(out), _p(argmax), int(relu), _p(y), _p(mean), _p(rstd), N, H, W, Cc, Ho, Wo,
-                                              pt, pl, _p(partial), _stream()), 'yolo_bn_pool_bwd_reduce')
+def bn_pool_bwd_reduce(dout, out, argmax, relu, y, mean, rstd, N, H, W, Cc, Ho, Wo, pt, pl, partial, gamma=None, beta=None):
+    check(_lib.load().yolo_bn_pool_bwd_reduce(_p(dout), _p(out), _p(argmax), int(relu), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                              N, H, W, Cc, Ho, Wo, pt, pl, _p(partial), _stream()), 'yolo_bn_pool_bwd_reduce')
 
 
 def bn_pool_bwd_apply(dout, out, argmax, relu, y, a1, mean, rstd, k1, k2, dy, N, H, W, Cc, Ho, Wo, pt, pl):
