@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one full training step (pack input, forward, YOLOv3 loss fwd+bwd, backward, [RCCL gradient all-reduce], RAdam+L2
-update, weight repack) on one synthetic COCO-shaped batch already resident in HBM.  Workload = BASELINE.json configs[1]:
+A step = one full training step (pack input, forward, YOLOv3 loss fwd+bwd, backward with the weight-gradient GEMMs on a second
+stream, [bucketed RCCL gradient all-reduce on a third], RAdam+L2 update, weight repack) on one synthetic COCO-shaped batch already resident in HBM.  Workload = BASELINE.json configs[1]:
 ResNet18-YOLOv3 416x416 bf16, 80 classes, batch 32 per GPU (weak scaling: global batch = 32 * N = configs[2] at N = 8).
 Prints ONE JSON line on rank 0.
 """
@@ -65,8 +65,6 @@ def conv_kernel_roofline(model, steps):
     """Average achieved TFLOP/s of the dominant kernel (the implicit-GEMM fwd/dgrad kernel) measured with HIP events on the
     launch stream in an eager (non-graph) pass: sum of algorithmic FLOPs of its launches / sum of their durations."""
     from yolov3_tensorflow_amd import engine, ops
-    convs = [op for op in model.g.tape if isinstance(op, engine.ConvOp)]
-    real = {ops.conv2d_fwd: ops.conv2d_fwd, ops.conv2d_dgrad: ops.conv2d_dgrad}
     records = []
 
     def timed(fn, flops_of):
@@ -84,6 +82,8 @@ def conv_kernel_roofline(model, steps):
 
     ops_fwd, ops_dg = ops.conv2d_fwd, ops.conv2d_dgrad
     ops.conv2d_fwd, ops.conv2d_dgrad = timed(ops_fwd, flops), timed(ops_dg, flops)
+    saved = model.overlap_wgrad
+    model.overlap_wgrad = False        # time each launch alone on the stream (no weight-gradient GEMM sharing the CUs)
     try:
         for _ in range(steps):
             model._fwd_bwd()
@@ -91,6 +91,7 @@ def conv_kernel_roofline(model, steps):
         torch.cuda.synchronize()
     finally:
         ops.conv2d_fwd, ops.conv2d_dgrad = ops_fwd, ops_dg
+        model.overlap_wgrad = saved
     t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in records)
     fl = sum(f for _, _, f in records)
     return fl / (t_ms * 1e-3) / 1e12, t_ms / max(len(records), 1), len(records) // max(steps, 1)
@@ -125,7 +126,9 @@ def main():
     ap.add_argument('--backbone', default='resnet-18')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay two hipGraphs instead of eager two-stream launches (measured slower: the '
+                    'forked weight-gradient branch is serialised under replay)')
+    ap.add_argument('--no-overlap', action='store_true', help='weight-gradient GEMMs on the main stream')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -142,7 +145,8 @@ def main():
 
     H = W = args.size
     model, loss, opt, grids = build_model(args.backbone, H, W, args.batch, args.classes, device)
-    model.use_hip_graph = not args.no_graph
+    model.use_hip_graph = bool(args.graph)
+    model.overlap_wgrad = not args.no_overlap
     if world > 1:
         from yolov3_tensorflow_amd import parallel
         parallel.setup_data_parallel(model)

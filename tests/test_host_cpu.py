@@ -106,6 +106,7 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
     loss = YOLOv3Loss([(12, 12), (6, 6), (3, 3)], 13, [[(1, 1)] * 3, [(1, 1)] * 2, [(1, 1)] * 3], 0.5, [(5, 5, .05, 3, 1)] * 3)
     m.compile(RAdam(), loss.loss)
     m.use_hip_graph = False
+    m.overlap_wgrad = False           # no HIP streams on the CPU
     mocked_kernels.clear()
     m._fwd_bwd()
     m._update()

@@ -181,6 +181,7 @@ def test_loss_curve_graph_replay():
     H = W = 160
     N, T, Cn = 4, 3, 4
     model, loss, opt, grids = build('resnet-18', H, W, N, Cn, rect=12)
+    model.use_hip_graph = True          # the two-hipGraph replay path (the default is eager two-stream execution)
     opt.lr = 1e-5
     w0 = model.get_weights()
     o = OracleTrainer('resnet-18', grids, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=12, rectified_loss_weight=[1.0, 1.0, 1.0], lr=1e-5)
@@ -216,3 +217,46 @@ def test_loss_curve_graph_replay():
     for a, b, same in zip(curve_gpu, curve_ref, same_assign):
         assert abs(a - b) <= (3e-3 if same else 6e-3) * abs(b), (curve_gpu, curve_ref, same_assign)
     assert np.median([abs(a - b) / abs(b) for a, b in zip(curve_gpu, curve_ref)]) <= 1.5e-3
+
+
+def test_eager_two_stream_and_bucketed_allreduce_match_serial():
+    """the default execution mode (eager, weight-gradient GEMMs on a second stream, late-layer gradient bucket all-reduced on a
+    communication stream during the rest of the backward pass; here a 1-rank RCCL group, i.e. the identity) must give the same weights
+    as single-stream serial execution, up to the float atomics' summation order in the weight gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import os
+    import torch.distributed as dist
+    H = W = 160
+    N, T, Cn = 4, 3, 4
+    images, labels = make_batch(N, H, W, T, Cn, seed=5)
+    results = []
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29741')
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        created = True
+    try:
+        for mode in ('serial', 'overlap'):
+            model, loss, opt, grids = build('resnet-18', H, W, N, Cn, rect=-1)
+            opt.lr = 1e-4
+            model.set_distributed(2, 0)             # exercise the data-parallel path ...
+            model.process_group = dist.group.WORLD  # ... on a 1-rank group: SUM is the identity, grad_scale = 1/2 in both runs
+            if mode == 'serial':
+                model.overlap_wgrad = False
+                model.overlap_allreduce = False
+            assert 0 < model.g.bucket_offset < model.g.ps.n
+            curve = [model.train_on_batch(images, labels) for _ in range(3)]
+            results.append((curve, model.get_weights()))
+    finally:
+        if created:
+            dist.destroy_process_group()
+    (c0, w0), (c1, w1) = results
+    # same arithmetic in both modes; only the order of the float atomics in the weight gradients differs
+    for a_, b_ in zip(c0, c1):
+        assert abs(a_ - b_) <= 2e-3 * abs(a_), (c0, c1)
+    ref = build('resnet-18', H, W, N, Cn, rect=-1)[0].get_weights()
+    for k in ('conv2d_20/kernel', 'conv2d_2/kernel', 'yolov3_head_8/kernel', 'batch_normalization_v1_5/gamma'):
+        d0, d1 = w0[k] - ref[k], w1[k] - ref[k]
+        assert np.linalg.norm(d0 - d1) <= 5e-2 * np.linalg.norm(d0), k

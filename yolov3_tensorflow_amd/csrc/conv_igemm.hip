@@ -15,7 +15,6 @@
 //                    so fragments are read with ds_read_b64_tr_b16 (hardware transpose); split over pixel ranges,
 //                    fp32 atomics into dW.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -84,12 +83,11 @@ constexpr int BK = 64;  // K elements per stage
 // s_barrier of each K-step; the XOR swizzle of the LDS image is applied on the SOURCE address (LDS-DMA writes lane-linear).
 // FAST gather (den == 1, single source, <= 32 taps): address = row base + tap offset, validity = one bit of a per-row tap mask, both
 // computed once per tile; the generic path (stride-2 data gradient, fused upsample+concat) recomputes coordinates per K-step.
-template <int BM, int BN, bool OUT_F32, bool FAST>
+template <int BM, int BN, int NSTAGE, bool OUT_F32, bool FAST>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* __restrict__ Wt, const float* __restrict__ bias,
                                                         void* __restrict__ Yv, int ldy, int accumulate,
                                                         float* __restrict__ stat_sum, float* __restrict__ stat_sq,
                                                         int Kout, int tiles_n) {
-  constexpr int NSTAGE = 2;                // 2 x (A + B) = 64 KB for 128 x 128: two workgroups per CU overlap each other's address math
   constexpr int WN = (BN == 128) ? 2 : 1;  // waves along channels
   constexpr int WM = 4 / WN;               // waves along pixels
   constexpr int PT = BM / WM / 16;         // 16-pixel MFMA tiles per wave
@@ -185,12 +183,18 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
     }
   };
 
-  issue_stage(0, 0);
+  constexpr int LPS = A_INSTR + B_INSTR;   // LDS-DMA loads per stage per wave
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st)
+    if (st < nk) issue_stage(st, st);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of stage kt has landed
-    __builtin_amdgcn_s_barrier();                       // ... every wave's has; and every wave has finished reading stage kt-1
+    // stage kt has landed once at most the loads of stages kt+1 .. kt+NSTAGE-2 are outstanding (vmcnt counts in issue order);
+    // in the last NSTAGE-2 iterations fewer stages are in flight, so drain completely there
+    if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPS) : "memory");
+    else                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave's part of stage kt is visible; stage kt-1 is no longer read
     asm volatile("" ::: "memory");
-    if (kt + 1 < nk) issue_stage(kt + 1, (kt + 1) % NSTAGE);   // in flight during the MFMAs below
+    if (kt + NSTAGE - 1 < nk) issue_stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);   // refills the buffer of stage kt-1
     compute_stage(kt % NSTAGE);
   }
 
@@ -492,22 +496,30 @@ int stat_rows_for(int M, int Kout) {
   return (M + t.bm - 1) / t.bm;      // one partial row per pixel tile
 }
 
-template <int BM, int BN, bool F32, bool FAST>
-int launch_tile2(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
+template <int BM, int BN, int NS, bool F32, bool FAST>
+int launch_tile3(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
                 hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
-  constexpr size_t lds = 2 * (BM * BK * 2 + BN * BK * 2);
+  constexpr size_t lds = NS * (BM * BK * 2 + BN * BK * 2);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, F32, FAST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, NS, F32, FAST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, F32, FAST>), dim3(tiles_m * tn), dim3(256), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
+  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, NS, F32, FAST>), dim3(tiles_m * tn), dim3(256), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
                      ssum, ssq, Kout, tn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
+}
+
+// Ring depth: 2 stages (64 KB for 128 x 128) so that two workgroups share a CU.  Measured on MI355X (tools/conv_bench.py, batch 32):
+// 3 / 4 stages with one workgroup per CU are 20-45 % slower -- waves per SIMD matter more than lookahead on these short K loops.
+template <int BM, int BN, bool F32, bool FAST>
+int launch_tile2(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
+                 hipStream_t st) {
+  return launch_tile3<BM, BN, 2, F32, FAST>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
 }
 
 template <int BM, int BN, bool F32>
@@ -579,10 +591,8 @@ extern "C" int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, c
   const int tiles_k = (g.Kg + WG_BKC - 1) / WG_BKC;
   const int tiles_c = (p->Cout + bco - 1) / bco;
   const int nsteps = (g.M + WG_BP - 1) / WG_BP;
-  if (split_k <= 0) {  // aim at ~3 workgroups per CU, at least 8 pixel-steps per workgroup
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("YOLO_WGRAD_BLOCKS"); target = e ? atoi(e) : 768; }
-    split_k = (target + tiles_k * tiles_c - 1) / (tiles_k * tiles_c);
+  if (split_k <= 0) {  // aim at ~2 workgroups per CU (measured best of 256..1536), at least 8 pixel-steps per workgroup
+    split_k = (512 + tiles_k * tiles_c - 1) / (tiles_k * tiles_c);
     const int max_split = (nsteps + 7) / 8;
     if (split_k > max_split) split_k = max_split;
     if (split_k < 1) split_k = 1;

@@ -175,6 +175,8 @@ class Graph(object):
         self.training = True
         self._alloc = []
         self._repack_table = None
+        self.wgrad_stream = None
+        self.bucket_cut, self.bucket_offset, self.on_bucket = -1, 0, None
 
     # ------------------------------------------------------------------------------------------------ allocation helpers
     def _buffer(self, shape, dtype=torch.bfloat16):
@@ -365,6 +367,14 @@ class Graph(object):
         for op in reversed(self.tape):
             op.plan_backward()
             self.bwd.append(op.backward)
+        # gradient bucket for data-parallel overlap: everything created from the first stride-32 convolution on (module512 + the three
+        # heads = ~70 % of the parameters) finishes its backward first; its slice of the flat gradient is [bucket_offset, n)
+        H32 = self.input_val.shape[1] // 32
+        for i, op in enumerate(self.tape):
+            if isinstance(op, ConvOp) and op.y.shape[1] == H32:
+                self.bucket_offset = op.y.wp.offset
+                self.bucket_cut = len(self.tape) - 1 - i          # index in the reversed launch list
+                break
 
     def refresh_dgrad_weights(self):
         """flipped/transposed bf16 weight copies for the data-gradient pass, all layers in one launch"""
@@ -386,8 +396,29 @@ class Graph(object):
             f()
 
     def run_backward(self):
-        for f in self.bwd:
+        """backward launch list.  With ``wgrad_stream`` set, every weight-gradient GEMM is enqueued on that second stream (forked by an
+        event after its dY is complete, joined once at the end): the MFMA-bound wgrads then overlap the bandwidth-bound BatchNorm
+        backward kernels and the tails of the data-gradient GEMMs.  Under hipGraph capture this becomes a forked graph."""
+        side = self.wgrad_stream
+        for i, f in enumerate(self.bwd):
             f()
+            if i == self.bucket_cut and self.on_bucket is not None:
+                self.on_bucket()          # every gradient of the late-layer bucket has been enqueued (main + wgrad stream)
+        if side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+
+    def on_wgrad_stream(self, fn):
+        """run fn() on the weight-gradient stream after everything enqueued so far on the current stream"""
+        side = self.wgrad_stream
+        if side is None:
+            fn()
+            return
+        main = torch.cuda.current_stream(self.dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            fn()
 
 
 # ==================================================================================================================== ops
@@ -453,7 +484,7 @@ class ConvOp(object):
             self.acc = [x.grad_init]
             x.grad_init = True
 
-    def backward(self):
+    def _wgrad(self):
         y = self.y
         s0 = None if self.src0 is None else self.src0.buf
         ops.conv2d_wgrad(y.p, self.src1.buf, y.dy, self.dw, src0=s0)
@@ -461,6 +492,10 @@ class ConvOp(object):
             C = y.shape[3]
             ops.bn_stats(y.dy, y.M, C, self.bpart)
             ops.reduce_partials(self.bpart, self.brow, 2 * C, C, self.dbias)
+
+    def backward(self):
+        y = self.y
+        self.g.on_wgrad_stream(self._wgrad)
         if not self.needs_dgrad():
             return
         x = y.x
@@ -504,7 +539,7 @@ class MixConvOp(object):
 
     def backward(self):
         y = self.y
-        ops.dwconv_mix_wgrad(y.mp, y.x.buf, y.dy, self.dw)
+        self.g.on_wgrad_stream(lambda: ops.dwconv_mix_wgrad(y.mp, y.x.buf, y.dy, self.dw))
         ops.dwconv_mix_dgrad(y.mp, y.dy, self.w, y.x.grad, accumulate=self.acc)
 
 
