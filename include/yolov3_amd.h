@@ -170,6 +170,12 @@ int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_global, const 
                       void* dlogits8_bf16, void* dlogits16_bf16, void* dlogits32_bf16, int* current_num, float* terms, float* total,
                       int* assign_out, float* resp_iou_out, void* workspace, void* stream);
 
+/* inference-side decode of one head (YOLOv3Decoder._decode_single_head, /root/reference/yolov3/yolov3_decoder.py:119-192, plus the score /
+ * arg-max class of /root/reference/yolov3/yolov3_post_process.py:53-59).  anchors_grid: device float32 [B][2] (w, h) in grid units.
+ * Outputs (device, any may be NULL): decoded [N][H][W][B][L], boxes [N][H][W][B][4] corners, score [N][H][W][B], cls_idx int32. */
+int yolo_decode_head(const float* logits, int N, int H, int W, int B, int L, int ldc, const float* anchors_grid, float eps, float* decoded,
+                     float* boxes, float* score, int* cls_idx, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * RAdam + L2 regularisation over the flat parameter buffer.  Replaces RAdam.get_updates
  * (/root/reference/utils/radam.py:56-107) and the Keras L2 regularisers (/root/reference/backbone/basic_backbone.py:41,64,76).

@@ -346,6 +346,45 @@ __global__ __launch_bounds__(9 * 64) void loss_finalize_kernel(LossCfg cfg, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- decode (inference)
+// YOLOv3Decoder._decode_single_head (yolov3_decoder.py:119-192) for one head: one lane per prediction.
+__global__ __launch_bounds__(256) void decode_head_kernel(const float* __restrict__ logits, int N, int H, int W, int B, int L, int ldc,
+                                                          const float* __restrict__ anchors /*[B][2] grid units (w,h)*/, float eps,
+                                                          float* __restrict__ decoded /*[N][H][W][B][L]*/, float* __restrict__ boxes /*[.][4]*/,
+                                                          float* __restrict__ score /*[N][H][W][B]*/, int* __restrict__ cls_idx) {
+  const size_t total = (size_t)N * H * W * B;
+  const float eps_lo = eps, eps_hi = 1.f - eps;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int b = (int)(i % B);
+    const size_t cellg = i / B;
+    const int col = (int)(cellg % W);
+    const int row = (int)((cellg / W) % H);
+    const float* t = logits + cellg * ldc + (size_t)b * L;
+    const Box p = decode_box(t, col, row, anchors[b * 2], anchors[b * 2 + 1], eps_lo, eps_hi);
+    const float conf = clipf_(sigmoidf_(t[4]), eps_lo, eps_hi);
+    float* d = decoded ? decoded + i * L : nullptr;
+    if (d) { d[0] = p.cx; d[1] = p.cy; d[2] = p.w; d[3] = p.h; d[4] = conf; }
+    if (boxes) { float* bx = boxes + i * 4; bx[0] = p.x0; bx[1] = p.y0; bx[2] = p.x1; bx[3] = p.y1; }
+    float best = 1.f;      // class probability defaults to 1, class 0 (yolov3_post_process.py:53-55)
+    int arg = 0;
+    const int C = L - 5;
+    if (C > 0) {
+      float mx = -INFINITY;
+      for (int k = 0; k < C; ++k) mx = fmaxf(mx, t[5 + k]);
+      float se = 0.f;
+      for (int k = 0; k < C; ++k) se += expf(t[5 + k] - mx);
+      best = -1.f;
+      for (int k = 0; k < C; ++k) {
+        const float pr = clipf_(expf(t[5 + k] - mx) / se, eps_lo, eps_hi);   // yolov3_decoder.py:189-191
+        if (d) d[5 + k] = pr;
+        if (pr > best) { best = pr; arg = k; }                               // np.argmax: first maximum
+      }
+    }
+    if (score) score[i] = C > 0 ? best * conf : conf;                          // yolov3_post_process.py:57-59
+    if (cls_idx) cls_idx[i] = arg;
+  }
+}
+
 inline int loss_nbx(const yolo_loss_config* c) {
   int nbx = 1;
   for (int h = 0; h < 3; ++h) {
@@ -399,6 +438,19 @@ extern "C" int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_glo
                      partial, inv_n);
   YOLO_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(9 * 64), 0, st, cfg, partial, N, nbx, inv_n, batch_global, current_num, terms, total);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_decode_head(const float* logits, int N, int H, int W, int B, int L, int ldc, const float* anchors_grid, float eps,
+                                float* decoded, float* boxes, float* score, int* cls_idx, void* stream) {
+  YOLO_CHECK_ARG(logits && anchors_grid && N > 0 && H > 0 && W > 0 && B > 0 && L >= 5 && ldc >= B * L, "bad argument");
+  YOLO_CHECK_ARG(decoded || boxes || score || cls_idx, "no output requested");
+  const size_t total = (size_t)N * H * W * B;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(decode_head_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, N, H, W, B, L, ldc, anchors_grid, eps,
+                     decoded, boxes, score, cls_idx);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

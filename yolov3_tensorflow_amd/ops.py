@@ -210,6 +210,11 @@ def loss_fwd_bwd(cfg, N, batch_global, logits, labels, current_num, terms, total
                                         _p(workspace), _stream()), 'yolo_loss_fwd_bwd')
 
 
+def decode_head(logits, N, H, W, B, L, ldc, anchors_grid, eps, decoded=None, boxes=None, score=None, cls_idx=None):
+    check(_lib.load().yolo_decode_head(_p(logits), N, H, W, B, L, ldc, _p(anchors_grid), eps, _p(decoded), _p(boxes), _p(score), _p(cls_idx),
+                                       _stream()), 'yolo_decode_head')
+
+
 def radam_schedule(sched, iterations, beta1, beta2, decay, warmup_coef):
     check(_lib.load().yolo_radam_schedule(_p(sched), _p(iterations), beta1, beta2, decay, warmup_coef, _stream()), 'yolo_radam_schedule')
 

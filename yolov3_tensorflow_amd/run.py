@@ -1,0 +1,98 @@
+"""Process entry with the reference's mode switch (run.py:123-181): FLAGS.mode in {train, test, predict, save_pb, save_serving}.
+    python -m yolov3_tensorflow_amd.run            (single GPU)
+    python -m torch.distributed.run --nproc-per-node 8 -m yolov3_tensorflow_amd.run     (data parallel)"""
+import logging
+import os
+import numpy as np
+
+from yolov3_tensorflow_amd import backend
+from yolov3_tensorflow_amd.configs import FLAGS
+from yolov3_tensorflow_amd.dataset.file_util import FileUtil
+from yolov3_tensorflow_amd.yolov3.trainer import YOLOv3Trainer
+from yolov3_tensorflow_amd.yolov3.yolov3_decoder import YOLOv3Decoder
+from yolov3_tensorflow_amd.yolov3.yolov3_post_process import YOLOv3PostProcessor
+
+backend.set_learning_phase(FLAGS.mode == 'train')     # reference :21-24
+backend.set_epsilon(1e-8)                              # reference :26
+np.random.seed(6)                                      # reference :27 (the weight-init seed 800 of :28 is the engine's default)
+
+
+def train(yolov3_trainer):
+    """reference :31-38"""
+    logging.info('loading training set: %s', FLAGS.train_label_path)
+    train_dataset = FileUtil.get_dataset(FLAGS.train_label_path, FLAGS.train_set_dir, image_size=FLAGS.input_image_size[0:2],
+                                         batch_size=FLAGS.batch_size, is_augment=FLAGS.is_augment, is_test=False)
+    yolov3_trainer.train(train_dataset, None)
+    logging.info('training finished')
+
+
+def _detect(yolov3_trainer, yolov3_decoder, images):
+    predictions = yolov3_trainer.predict(images)
+    return yolov3_decoder.decode(predictions)
+
+
+def test(yolov3_trainer, yolov3_decoder, save_path=None):
+    """reference :41-80"""
+    test_set = FileUtil.get_dataset(FLAGS.test_label_path, FLAGS.test_set_dir, image_size=FLAGS.input_image_size[0:2],
+                                    batch_size=FLAGS.batch_size, is_augment=False, is_test=True)
+    input_box_size = np.tile(FLAGS.input_image_size[1::-1], [2])          # [W, H, W, H]
+    results = []
+    for images, labels, image_paths in test_set:
+        heads = _detect(yolov3_trainer, yolov3_decoder, images)
+        for n, (image, image_path) in enumerate(zip(images, image_paths)):
+            hs = YOLOv3PostProcessor.filter_boxes(heads[0][1][n], heads[0][2][n], heads[1][1][n], heads[1][2][n], heads[2][1][n],
+                                                  heads[2][2][n], FLAGS.confidence_thresh)
+            nms_boxes = YOLOv3PostProcessor.apply_nms(hs, FLAGS.nms_thresh)
+            in_boxes = YOLOv3PostProcessor.resize_boxes(nms_boxes, target_size=input_box_size)
+            results.append((image_path, in_boxes))
+            if save_path is not None:
+                YOLOv3PostProcessor.visualize(image, in_boxes, src_box_size=input_box_size,
+                                              image_path=os.path.join(save_path, os.path.basename(image_path)))
+    return results
+
+
+def predict(yolov3_trainer, yolov3_decoder, image_paths, save_path):
+    """reference :83-120"""
+    from PIL import Image
+    input_box_size = np.tile(FLAGS.input_image_size[1::-1], [2])
+    for image_path in image_paths:
+        rgb = np.asarray(Image.open(image_path).convert('RGB'))
+        boxed, _ = FileUtil.letterbox(rgb, np.zeros((0, 5), np.float32), FLAGS.input_image_size[0:2])
+        image = (boxed.astype(np.float32) / 255.0)[..., ::-1]
+        heads = _detect(yolov3_trainer, yolov3_decoder, np.expand_dims(image, 0))
+        hs = YOLOv3PostProcessor.filter_boxes(heads[0][1][0], heads[0][2][0], heads[1][1][0], heads[1][2][0], heads[2][1][0], heads[2][2][0],
+                                              FLAGS.confidence_thresh)
+        in_boxes = YOLOv3PostProcessor.resize_boxes(YOLOv3PostProcessor.apply_nms(hs, FLAGS.nms_thresh), target_size=input_box_size)
+        YOLOv3PostProcessor.visualize(image, in_boxes, src_box_size=input_box_size, image_path=os.path.join(save_path, os.path.basename(image_path)))
+
+
+def run():
+    """reference :123-181"""
+    if FLAGS.gpu_mode == YOLOv3Trainer.CPU_MODE:
+        raise RuntimeError("gpu_mode 'cpu' is not available on the MI355X-native path")
+    logging.basicConfig(level=logging.INFO)
+    yolov3_trainer = YOLOv3Trainer()
+    if FLAGS.mode == 'train':
+        train(yolov3_trainer)
+    elif FLAGS.mode in ('test', 'predict'):
+        yolov3_decoder = YOLOv3Decoder(head_grid_sizes=FLAGS.head_grid_sizes, class_num=FLAGS.class_num, anchor_boxes=FLAGS.anchor_boxes)
+        save_path = FLAGS.save_path
+        if save_path is not None and not os.path.exists(save_path):
+            os.makedirs(save_path)                      # the reference raises before it can create the directory (run.py:154-157)
+        if FLAGS.mode == 'test':
+            test(yolov3_trainer, yolov3_decoder, save_path)
+        else:
+            root = FLAGS.image_root_path
+            if root is None or not os.path.isdir(root) or save_path is None:
+                raise ValueError('image_root_path must be a directory and save_path must be set')
+            predict(yolov3_trainer, yolov3_decoder, [os.path.join(root, f) for f in sorted(os.listdir(root)) if f.endswith('.jpg')], save_path)
+    elif FLAGS.mode == 'save_pb':
+        yolov3_trainer.save_mobile()
+    elif FLAGS.mode == 'save_serving':
+        yolov3_trainer.save_serving()
+    else:
+        raise ValueError('Mode Error!')
+
+
+if __name__ == '__main__':
+    run()
