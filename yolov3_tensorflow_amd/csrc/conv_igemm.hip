@@ -27,20 +27,29 @@ struct Gather {
   int Ho, Wo;          // row space
   int S, RS;           // kernel width, taps
   int smul, pad_h, pad_w, den;  // src coord = (row * smul - pad + tap) / den  (valid iff divisible and in range)
-  int M;               // rows
+  int M;               // rows (< 2^24: row decode uses float reciprocals)
   int Kg;              // GEMM K = RS * (C0 + C1)
+  float rhw, rw;       // 1 / (Ho * Wo), 1 / Wo
+  int magicS;          // tap / S == (tap * magicS) >> 16 for tap < 128
 };
 
 struct RowInfo { int n, hb, wb; };
 
+// q = m / d, r = m % d with a float reciprocal + one correction step (exact for m < 2^24): ~8 instructions instead of the ~40 of an
+// integer division -- the tile prologue decodes 4 rows per lane and was dominated by divisions
+__device__ __forceinline__ void fast_divmod(int m, int d, float rd, int& q, int& r) {
+  q = (int)((float)m * rd);
+  r = m - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+}
+
 __device__ __forceinline__ RowInfo decode_row(const Gather& g, int m) {
   RowInfo r;
   if (m >= g.M) { r.n = 0; r.hb = -(1 << 28); r.wb = -(1 << 28); return r; }
-  int hw = g.Ho * g.Wo;
-  r.n = m / hw;
-  int rem = m - r.n * hw;
-  int ho = rem / g.Wo;
-  int wo = rem - ho * g.Wo;
+  int rem, ho, wo;
+  fast_divmod(m, g.Ho * g.Wo, g.rhw, r.n, rem);
+  fast_divmod(rem, g.Wo, g.rw, ho, wo);
   r.hb = ho * g.smul - g.pad_h;
   r.wb = wo * g.smul - g.pad_w;
   return r;
@@ -117,11 +126,16 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
     rows[j] = decode_row(g, m0 + (wave * A_INSTR + j) * 8 + lrow);
     if constexpr (FAST) {
       rbase[j] = ((rows[j].n * g.Hs + rows[j].hb) * g.Ws + rows[j].wb) * g.C1;
+      // tap (tr, ts) is inside the image iff row tr and column ts are: 3 + 3 range tests per row instead of 9 x 4; bits 0..15 = rows,
+      // bits 16..31 = columns (R, S <= 9)
       unsigned mk = 0;
-      for (int t = 0; t < g.RS; ++t) {
-        const int tr = t / g.S, ts = t - tr * g.S;
-        const int hn = rows[j].hb + tr, wn = rows[j].wb + ts;
-        mk |= ((hn >= 0) & (hn < g.Hs) & (wn >= 0) & (wn < g.Ws)) ? (1u << t) : 0u;
+      for (int t = 0; t * g.S < g.RS; ++t) {
+        const int hn = rows[j].hb + t;
+        mk |= ((hn >= 0) & (hn < g.Hs)) ? (1u << t) : 0u;
+      }
+      for (int t = 0; t < g.S; ++t) {
+        const int wn = rows[j].wb + t;
+        mk |= ((wn >= 0) & (wn < g.Ws)) ? (0x10000u << t) : 0u;
       }
       vmask[j] = mk;
     }
@@ -146,13 +160,13 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
     const int tap = q >> g.lgC8;
     const int c = (q & cmask) << 3;
     const bool kvalid = tap < g.RS;
-    const int tr = tap / g.S, ts = tap - tr * g.S;
+    const int tr = (tap * g.magicS) >> 16, ts = tap - tr * g.S;
     if constexpr (FAST) {
       const int toff = (tr * g.Ws + ts) * g.C1 + c;
-      const unsigned tbit = kvalid ? (1u << tap) : 0u;
+      const unsigned tbits = kvalid ? ((1u << tr) | (0x10000u << ts)) : 0xffffffffu;   // ~0 never matches: both bits must be set
 #pragma unroll
       for (int j = 0; j < A_INSTR; ++j) {
-        const bf16_t* p = (vmask[j] & tbit) ? g.src1 + (rbase[j] + toff) : reinterpret_cast<const bf16_t*>(&g_zero16);
+        const bf16_t* p = (kvalid && (vmask[j] & tbits) == tbits) ? g.src1 + (rbase[j] + toff) : reinterpret_cast<const bf16_t*>(&g_zero16);
         __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(sA + j * 1024), 16, 0, 0);
       }
     } else {
@@ -206,46 +220,73 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
 
+  if constexpr (OUT_F32) {   // float32 logits (+ bias): 16 bytes per lane, written straight from the accumulators
 #pragma unroll
-  for (int b = 0; b < PT; ++b) {
-    const int m = m0 + wm * (PT * 16) + b * 16 + (lane & 15);
-    const bool mv = m < g.M;
+    for (int b = 0; b < PT; ++b) {
+      const int m = m0 + wm * (PT * 16) + b * 16 + (lane & 15);
+      if (m < g.M) {
 #pragma unroll
-    for (int a = 0; a < CT; ++a) {
-      const int co = n0 + wn * (CT * 16) + a * 16 + cq;
-      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-      if (bias) {
+        for (int a = 0; a < CT; ++a) {
+          const int co = n0 + wn * (CT * 16) + a * 16 + cq;
+          float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+          if (bias) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += bias[co + j];
-      }
-      if (mv) {
-        if constexpr (OUT_F32) {
+            for (int j = 0; j < 4; ++j) v[j] += bias[co + j];
+          }
           float* y = reinterpret_cast<float*>(Yv) + (size_t)m * ldy + co;
           if (accumulate) { float4 o = *reinterpret_cast<float4*>(y); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
           *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          bf16_t* y = reinterpret_cast<bf16_t*>(Yv) + (size_t)m * ldy + co;
-          if (accumulate) {
-            uint2 o = *reinterpret_cast<uint2*>(y);
-            v[0] += __uint_as_float(o.x << 16); v[1] += __uint_as_float(o.x & 0xffff0000u);
-            v[2] += __uint_as_float(o.y << 16); v[3] += __uint_as_float(o.y & 0xffff0000u);
-          }
-          uint2 o;
-          o.x = pack_bf2(v[0], v[1]);
-          o.y = pack_bf2(v[2], v[3]);
-          *reinterpret_cast<uint2*>(y) = o;
-          if (stat_sum) {  // statistics of the values as stored (bf16-rounded)
-            float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
-            float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
-            ssum[a][0] += r0; ssum[a][1] += r1; ssum[a][2] += r2; ssum[a][3] += r3;
-            ssq[a][0] += r0 * r0; ssq[a][1] += r1 * r1; ssq[a][2] += r2 * r2; ssq[a][3] += r3 * r3;
-          }
         }
       }
     }
-  }
-  if (stat_sum) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
+  } else {
+    // bf16 activations: the tile is transposed through LDS (free now) so that every store instruction writes whole 128/256-byte
+    // NHWC rows -- straight from the accumulators each instruction wrote 16 scattered 32-byte segments, which cost more than the
+    // MFMAs of the whole tile on the 64-channel layers (ablation: 39 of 70 us)
+    constexpr int OLD = BN * 2 + 16;                  // LDS row stride in bytes (16-byte pad: conflict-free 8-byte writes)
     __syncthreads();                                  // every wave is done with the operand ring
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      const int pl = wm * (PT * 16) + b * 16 + (lane & 15);
+#pragma unroll
+      for (int a = 0; a < CT; ++a) {
+        const int cl = wn * (CT * 16) + a * 16 + cq;
+        uint2 o;
+        o.x = pack_bf2(acc[a][b][0], acc[a][b][1]);
+        o.y = pack_bf2(acc[a][b][2], acc[a][b][3]);
+        *reinterpret_cast<uint2*>(smem + pl * OLD + cl * 2) = o;
+        if (stat_sum && !accumulate && m0 + pl < g.M) {   // statistics of the values as stored (bf16-rounded)
+          const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
+          const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+          ssum[a][0] += r0; ssum[a][1] += r1; ssum[a][2] += r2; ssum[a][3] += r3;
+          ssq[a][0] += r0 * r0; ssq[a][1] += r1 * r1; ssq[a][2] += r2 * r2; ssq[a][3] += r3 * r3;
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                       // 16-byte chunks per row
+    bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
+    for (int i = tid; i < BM * CPR; i += 256) {
+      const int row = i / CPR, ch = i - row * CPR;
+      const int m = m0 + row;
+      if (m < g.M) {
+        uint4 v = *reinterpret_cast<const uint4*>(smem + row * OLD + ch * 16);
+        bf16_t* yp = Y + (size_t)m * ldy + n0 + ch * 8;
+        if (accumulate) {                             // gradient fan-in: y += tile (float32 add, one rounding)
+          float a8[8], b8[8];
+          unpack_bf8(v, a8);
+          unpack_bf8(*reinterpret_cast<const uint4*>(yp), b8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a8[j] += b8[j];
+          v = pack_bf8(a8);
+        }
+        *reinterpret_cast<uint4*>(yp) = v;
+      }
+    }
+  }
+
+  if (stat_sum) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
+    __syncthreads();                                  // every wave is done with the staged output tile
     float* red = reinterpret_cast<float*>(smem);      // [2][WM][BN]
 #pragma unroll
     for (int a = 0; a < CT; ++a)
@@ -295,14 +336,6 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* img, int p0, int col0, i
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
-// m -> (n, ho, wo) with float reciprocals + one correction step (exact for m < 2^24; the launcher checks M)
-__device__ __forceinline__ void fast_divmod(int m, int d, float rd, int& q, int& r) {
-  q = (int)((float)m * rd);
-  r = m - q * d;
-  if (r < 0) { --q; r += d; }
-  if (r >= d) { ++q; r -= d; }
-}
-
 template <int BCO>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(Gather g, const bf16_t* __restrict__ dY, int ldy,
                                                           float* __restrict__ dW, int Kout, int steps_per_split, float rhw, float rw) {
@@ -329,7 +362,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(Gather g, const bf16_t
     const int tap = q >> g.lgC8;
     x_c[j] = (q & ((1 << g.lgC8) - 1)) << 3;
     x_kv[j] = tap < g.RS;
-    x_tr[j] = tap / g.S;
+    x_tr[j] = (min(tap, 127) * g.magicS) >> 16;
     x_ts[j] = tap - x_tr[j] * g.S;
     y_c[j] = co0 + ch * 8;
     y_cv[j] = (BCO == 128 || ch < 8) && y_c[j] < Kout;
@@ -352,8 +385,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(Gather g, const bf16_t
       const bf16_t* py = px;
       if (m < g.M) {
         int n, rem, ho, wo;
-        fast_divmod(m, hw, rhw, n, rem);
-        fast_divmod(rem, g.Wo, rw, ho, wo);
+        fast_divmod(m, hw, g.rhw, n, rem);
+        fast_divmod(rem, g.Wo, g.rw, ho, wo);
         RowInfo r;
         r.n = n; r.hb = ho * g.smul - g.pad_h; r.wb = wo * g.smul - g.pad_w;
         px = gather_addr(g, r, x_tr[j], x_ts[j], x_c[j], x_kv[j]);
@@ -465,6 +498,7 @@ int check_problem(const yolo_conv_problem* p) {
   YOLO_CHECK_ARG(p->pad_t >= 0 && p->pad_l >= 0 && p->pad_t < p->R && p->pad_l < p->S, "bad padding");
   // every output pixel must map inside the padded input
   YOLO_CHECK_ARG((p->Ho - 1) * p->stride - p->pad_t < p->H && (p->Wo - 1) * p->stride - p->pad_l < p->W, "Ho/Wo too large");
+  YOLO_CHECK_ARG((size_t)p->N * p->H * p->W < (1u << 24) && (size_t)p->N * p->Ho * p->Wo < (1u << 24), "row decode needs N*H*W < 2^24");
   YOLO_CHECK_ARG((size_t)p->N * p->H * p->W * p->Cin < (1ull << 31) && (size_t)p->N * p->Ho * p->Wo * p->Cout < (1ull << 31),
                  "tensor too large for 32-bit row indexing");
   return YOLO_OK;
@@ -478,6 +512,7 @@ Gather fwd_gather(const yolo_conv_problem* p, const void* src0, const void* src1
   g.Ho = p->Ho; g.Wo = p->Wo; g.S = p->S; g.RS = p->R * p->S;
   g.smul = p->stride; g.pad_h = p->pad_t; g.pad_w = p->pad_l; g.den = 1;
   g.M = p->N * p->Ho * p->Wo; g.Kg = p->R * p->S * p->Cin;
+  g.rhw = 1.0f / (float)(g.Ho * g.Wo); g.rw = 1.0f / (float)g.Wo; g.magicS = 65536 / g.S + 1;
   return g;
 }
 
@@ -525,7 +560,7 @@ int launch_tile2(const Gather& g, const void* w, const float* bias, void* y, int
 template <int BM, int BN, bool F32>
 int launch_tile(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
                 hipStream_t st) {
-  const bool fast = g.den == 1 && g.C0 == 0 && g.RS <= 32 &&
+  const bool fast = g.den == 1 && g.C0 == 0 && g.S <= 9 && g.RS <= 81 &&
                     (size_t)g.Hs * g.Ws * g.C1 * (size_t)(g.M / (g.Ho * g.Wo) + 1) < (1ull << 31);
   if (fast) return launch_tile2<BM, BN, F32, true>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
   return launch_tile2<BM, BN, F32, false>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
@@ -576,6 +611,8 @@ extern "C" int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, con
   g.Ho = p->H; g.Wo = p->W; g.S = p->S; g.RS = p->R * p->S;
   g.smul = 1; g.pad_h = p->R - 1 - p->pad_t; g.pad_w = p->S - 1 - p->pad_l; g.den = p->stride;
   g.M = p->N * p->H * p->W; g.Kg = p->R * p->S * p->Cout;
+  g.rhw = 1.0f / (float)(g.Ho * g.Wo); g.rw = 1.0f / (float)g.Wo; g.magicS = 65536 / g.S + 1;
+  YOLO_CHECK_ARG(g.M < (1 << 24), "row decode needs N*H*W < 2^24");
   return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate, nullptr, nullptr, p->Cin, (hipStream_t)stream);
 }
 
