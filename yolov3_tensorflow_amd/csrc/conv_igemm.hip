@@ -92,20 +92,20 @@ constexpr int BK = 64;  // K elements per stage
 // s_barrier of each K-step; the XOR swizzle of the LDS image is applied on the SOURCE address (LDS-DMA writes lane-linear).
 // FAST gather (den == 1, single source, <= 32 taps): address = row base + tap offset, validity = one bit of a per-row tap mask, both
 // computed once per tile; the generic path (stride-2 data gradient, fused upsample+concat) recomputes coordinates per K-step.
-template <int BM, int BN, int NSTAGE, bool OUT_F32, bool FAST>
-__global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* __restrict__ Wt, const float* __restrict__ bias,
+template <int BM, int BN, int NSTAGE, bool OUT_F32, bool FAST, int NW>
+__global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16_t* __restrict__ Wt, const float* __restrict__ bias,
                                                         void* __restrict__ Yv, int ldy, int accumulate,
                                                         float* __restrict__ stat_sum, float* __restrict__ stat_sq,
                                                         int Kout, int tiles_n) {
   constexpr int WN = (BN == 128) ? 2 : 1;  // waves along channels
-  constexpr int WM = 4 / WN;               // waves along pixels
+  constexpr int WM = NW / WN;              // waves along pixels
   constexpr int PT = BM / WM / 16;         // 16-pixel MFMA tiles per wave
   constexpr int CT = BN / WN / 16;         // 16-channel MFMA tiles per wave (= 4)
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int A_INSTR = BM / 32;         // LDS-DMA instructions per wave per stage (8 rows x 128 B each)
-  constexpr int B_INSTR = BN / 32;
+  constexpr int A_INSTR = BM / (8 * NW);   // LDS-DMA instructions per wave per stage (8 rows x 128 B each)
+  constexpr int B_INSTR = BN / (8 * NW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
     __syncthreads();
     constexpr int CPR = BN / 8;                       // 16-byte chunks per row
     bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
-    for (int i = tid; i < BM * CPR; i += 256) {
+    for (int i = tid; i < BM * CPR; i += NW * 64) {
       const int row = i / CPR, ch = i - row * CPR;
       const int m = m0 + row;
       if (m < g.M) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(Gather g, const bf16_t* 
         }
       }
     __syncthreads();
-    for (int cl = tid; cl < BN; cl += 256) {
+    for (int cl = tid; cl < BN; cl += NW * 64) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) { s += red[w * BN + cl]; q += red[(WM + w) * BN + cl]; }
@@ -524,6 +524,8 @@ TileCfg pick_tile(int M, int Kout) {
   t.bn = (Kout % 128 == 0) ? 128 : 64;
   const long tiles128 = (long)((M + 127) / 128) * (Kout / t.bn);
   t.bm = tiles128 < 512 ? 64 : 128;
+  // still fewer than 2 workgroups per CU with 64 x 128 tiles (the 13 x 13 layers at batch 32): 64 x 64 tiles (measured +8 %)
+  if (t.bm == 64 && t.bn == 128 && (long)((M + 63) / 64) * (Kout / 128) < 512) t.bn = 64;
   return t;
 }
 int stat_rows_for(int M, int Kout) {
@@ -531,30 +533,36 @@ int stat_rows_for(int M, int Kout) {
   return (M + t.bm - 1) / t.bm;      // one partial row per pixel tile
 }
 
-template <int BM, int BN, int NS, bool F32, bool FAST>
+template <int BM, int BN, int NS, bool F32, bool FAST, int NW>
 int launch_tile3(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
                 hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
-  constexpr size_t lds = NS * (BM * BK * 2 + BN * BK * 2);
+  constexpr size_t lds_ring = NS * (BM * BK * 2 + BN * BK * 2), lds_out = (size_t)BM * (BN * 2 + 16);
+  constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, NS, F32, FAST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, NS, F32, FAST>), dim3(tiles_m * tn), dim3(256), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
+  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW>), dim3(tiles_m * tn), dim3(NW * 64), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
                      ssum, ssq, Kout, tn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
 
-// Ring depth: 2 stages (64 KB for 128 x 128) so that two workgroups share a CU.  Measured on MI355X (tools/conv_bench.py, batch 32):
-// 3 / 4 stages with one workgroup per CU are 20-45 % slower -- waves per SIMD matter more than lookahead on these short K loops.
+// Ring depth: 2 stages (64 KB for 128 x 128: two workgroups per CU; 48 KB for 128 x 64 / 64 x 128: three).  Measured on MI355X
+// (tools/conv_bench.py, batch 32): 3 / 4 stages at fewer workgroups per CU are 20-45 % slower -- waves per SIMD matter more than lookahead
+// on these short K loops -- and a ring of finer 32-wide units (64-byte rows) is 30-80 % slower: half-line LDS-DMA pieces double the L2
+// requests, rows must stay whole 128-byte lines.
 template <int BM, int BN, bool F32, bool FAST>
 int launch_tile2(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
                  hipStream_t st) {
-  return launch_tile3<BM, BN, 2, F32, FAST>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+  // 128 x 128 tiles run with 8 waves (each 32 pixels x 64 channels): same LDS, twice the waves per SIMD; measured 128-channel layer
+  // fwd 56 -> 49 us, dgrad 48 -> 38 us; on 128 x 64 tiles it is mixed (fwd slower), so those keep 4 waves
+  if constexpr (BM == 128 && BN == 128) return launch_tile3<BM, BN, 2, F32, FAST, 8>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+  else return launch_tile3<BM, BN, 2, F32, FAST, 4>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
 }
 
 template <int BM, int BN, bool F32>
