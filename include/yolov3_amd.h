@@ -60,6 +60,12 @@ int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, const void* w_
 /* dw[Cout][R][S][Cin] += x^T * dy (float32 atomics; the caller zeroes dw once per step).  split_k <= 0 = auto. */
 int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
                       int split_k, void* stream);
+/* The same gradient without atomics (the training path): every pixel split stores its partial [Cout][R][S][Cin] slab into
+ * `workspace` (>= yolo_conv2d_wgrad_workspace_bytes(p) bytes, 16-byte aligned, may be shared by consecutive calls on one stream),
+ * a second launch sums the slabs: dw = (accumulate ? dw : 0) + sum.  Deterministic for a given problem. */
+size_t yolo_conv2d_wgrad_workspace_bytes(const yolo_conv_problem* p);
+int yolo_conv2d_wgrad_reduce(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
+                             void* workspace, size_t workspace_bytes, int accumulate, void* stream);
 /* bf16 [Cout][R][S][Cin] -> bf16 [Cin][R][S][Cout] with flipped taps (operand layout of yolo_conv2d_dgrad). */
 int yolo_repack_dgrad_weights(const void* w_fwd, void* w_dgrad, int Cout, int R, int S, int Cin, void* stream);
 /* the same for every layer in ONE launch.  table_dev: device int32 [nlayers][8] = {src element offset into w_fwd_flat, dst element

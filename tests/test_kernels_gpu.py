@@ -96,6 +96,17 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     dw2 = torch.zeros_like(dw)
     ops.conv2d_wgrad(p, xd, dyd, dw2, split_k=3)
     torch.testing.assert_close(dw2.cpu(), dw_ref, rtol=1e-3, atol=1e-4 * max(scale, 1.0))
+    # two-phase path (the one training uses): split slabs in a workspace + summing pass, overwrites dw; accumulate adds
+    ws = torch.empty(max(ops.conv2d_wgrad_workspace_bytes(p), 16) // 4, device=dev)
+    dw3 = torch.full_like(dw, 7.0)
+    ops.conv2d_wgrad_reduce(p, xd, dyd, dw3, ws)
+    torch.testing.assert_close(dw3.cpu(), dw_ref, rtol=1e-3, atol=1e-4 * max(scale, 1.0))
+    ops.conv2d_wgrad_reduce(p, xd, dyd, dw3, ws, accumulate=True)
+    torch.testing.assert_close(dw3.cpu(), 2 * dw_ref, rtol=1e-3, atol=2e-4 * max(scale, 1.0))
+    dw4 = torch.empty_like(dw)
+    ops.conv2d_wgrad_reduce(p, xd, dyd, dw4, ws)
+    ops.conv2d_wgrad_reduce(p, xd, dyd, dw3, ws)
+    assert torch.equal(dw3, dw4), 'two-phase weight gradient must be run-to-run deterministic'
 
     if Cin % 64 == 0:
         w_dg = torch.empty(Cin, k, k, Cout, dtype=torch.bfloat16, device=dev)
@@ -130,6 +141,10 @@ def test_conv_fused_upsample_concat(dev):
     dw = torch.zeros(Cout, 1, 1, C0 + C1, device=dev)
     ops.conv2d_wgrad(p, b.to(dev), dy.to(dev), dw, src0=a.to(dev))
     torch.testing.assert_close(dw.cpu(), wr.grad.permute(3, 0, 1, 2), rtol=1e-3, atol=1e-3)
+    ws = torch.empty(max(ops.conv2d_wgrad_workspace_bytes(p), 16) // 4, device=dev)
+    dw_r = torch.empty_like(dw)
+    ops.conv2d_wgrad_reduce(p, b.to(dev), dy.to(dev), dw_r, ws, src0=a.to(dev))
+    torch.testing.assert_close(dw_r.cpu(), wr.grad.permute(3, 0, 1, 2), rtol=1e-3, atol=1e-3)
     # dgrad over the virtual concat, then the split kernel
     pd = ops.conv_problem(N, H, W, C0 + C1, Cout, 1, 1, 'same')
     w_dg = torch.empty(C0 + C1, 1, 1, Cout, dtype=torch.bfloat16, device=dev)

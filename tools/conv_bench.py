@@ -38,7 +38,7 @@ def main():
         y = torch.empty(N, p.Ho, p.Wo, Cout, dtype=torch.bfloat16, device=dev)
         dy = torch.randn(N, p.Ho, p.Wo, Cout, device=dev).to(torch.bfloat16)
         dx = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
-        dw = torch.zeros(Cout, k, k, Cin, device=dev)
+        dw = torch.zeros((160 if os.environ.get('YOLO_WGRAD_EPI') == '3' else 1) * Cout, k, k, Cin, device=dev)
         rows = ops.conv2d_stat_rows(p)
         ss, sq = torch.zeros(rows, Cout, device=dev), torch.zeros(rows, Cout, device=dev)
         flops = 2.0 * N * p.Ho * p.Wo * Cout * Cin * k * k

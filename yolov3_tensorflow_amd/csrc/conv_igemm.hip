@@ -35,6 +35,9 @@ struct Gather {
 
 struct RowInfo { int n, hb, wb; };
 
+// full-rate 24-bit multiply-add (operands < 2^24; the 32-bit v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
+
 // q = m / d, r = m % d with a float reciprocal + one correction step (exact for m < 2^24): ~8 instructions instead of the ~40 of an
 // integer division -- the tile prologue decodes 4 rows per lane and was dominated by divisions
 __device__ __forceinline__ void fast_divmod(int m, int d, float rd, int& q, int& r) {
@@ -63,6 +66,13 @@ __device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA of 16 bytes per lane through a raw buffer descriptor over [base, base + bytes): lanes whose byte offset is out of range
+// (e.g. 0x80000000) write zeros -- probed on gfx950 (tools/probes/buffer_lds_probe.hip).  The descriptor is wave-uniform (4 SGPRs).
+__device__ __forceinline__ void buffer_load_lds16(const void* base, unsigned bytes, void* lds, unsigned voffset) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)lds, 16, voffset, 0, 0, 0);
+}
 
 // address of one 16-byte k-chunk of one row, or the zero chunk
 __device__ __forceinline__ const bf16_t* gather_addr(const Gather& g, const RowInfo& r, int tap_r, int tap_s, int c, bool kvalid) {
@@ -336,28 +346,41 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* img, int p0, int col0, i
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
-template <int BCO>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(Gather g, const bf16_t* __restrict__ dY, int ldy,
-                                                          float* __restrict__ dW, int Kout, int steps_per_split, float rhw, float rw) {
+// per-stage advance of the pixel cursor (64 pixels): 64 = dn * (Ho*Wo) + dh * Wo + dw, and the byte sizes of the two streamed tensors
+struct WgradStep { int dn, dh, dw; unsigned x_bytes, y_bytes; long long slab; };   // slab > 0: split z stores to dW + z * slab (no atomics)
+
+// Weight gradient dW[co][kcol] = sum over pixels dY[pix][co] * X[pix][kcol] (kcol = (tap, ci)): NW waves = 2 along co x NW/2 along
+// kcol, split-K over pixel ranges (blockIdx.z), fp32 atomics into dW.
+// CAT = false (single source): the gather runs division-free -- every lane keeps the (n, ho, wo) cursor of its rows and advances it by
+// the constant 64-pixel step, and the loads go through buffer descriptors (buffer_load ... lds), whose range check supplies the zeros of
+// padding / tails (offset 0x80000000 = out of range) instead of a selected zero-page pointer: ~55 VALU per stage instead of ~200 with
+// a dozen quarter-rate 32-bit multiplies, which had made the kernel VALU-bound (SQ_INSTS_VALU / SQ_INSTS_MFMA = 11.7).
+// CAT = true (fused upsample + concat source) keeps the generic pointer path.
+template <int BCO, int NW, bool CAT>
+__global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(Gather g, const bf16_t* __restrict__ dY, int ldy,
+                                                          float* __restrict__ dW, int Kout, int steps_per_split, WgradStep ws) {
   constexpr int IMG = WG_BP * 256;          // bytes of one [64 pix][128 col] image
-  constexpr int COT = BCO / 32;             // 16-row co tiles per wave (waves: 2 along co x 2 along kcol)
+  constexpr int COT = BCO / 32;             // 16-row co tiles per wave
+  constexpr int WC = NW / 2;                // waves along kcol
+  constexpr int XT = WG_BKC / WC / 16;      // 16-column kcol tiles per wave
+  constexpr int IPW = 16 / NW;              // LDS-DMA instructions per wave per image (4 rows x 256 B each)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;  // wave tile: co [wr*BCO/2, +BCO/2) x kcol [wc*64, +64)
+  const int wr = wave / WC, wc = wave % WC;  // wave tile: co [wr*BCO/2, +BCO/2) x kcol [wc*16*XT, +16*XT)
   const int kc0 = blockIdx.x * WG_BKC, co0 = blockIdx.y * BCO;
   const int nsteps = (g.M + WG_BP - 1) / WG_BP;
   const int s_begin = blockIdx.z * steps_per_split;
   const int s_end = min(nsteps, s_begin + steps_per_split);
   if (s_begin >= s_end) return;
 
-  // LDS-DMA geometry: instruction j of this wave covers image rows (wave*4 + j)*4 .. +3; lane -> row +(lane >> 4), slot lane & 15,
-  // which holds chunk slot ^ f(row) with f(row) = ((lane >> 4) << 2) | j
+  // LDS-DMA geometry: instruction j of this wave covers image rows (wave*IPW + j)*4 .. +3; lane -> row +(lane >> 4), slot lane & 15,
+  // which holds chunk slot ^ f(row) with f(row) = ((lane >> 4) << 2) | ((wave*IPW + j) & 3)
   const int lr = lane >> 4, slot = lane & 15;
-  int x_tr[4], x_ts[4], x_c[4], y_c[4];
-  bool x_kv[4], y_cv[4];
+  int x_tr[IPW], x_ts[IPW], x_c[IPW], y_c[IPW];
+  bool x_kv[IPW], y_cv[IPW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ch = slot ^ ((lr << 2) | j);
+  for (int j = 0; j < IPW; ++j) {
+    const int ch = slot ^ ((lr << 2) | ((wave * IPW + j) & 3));
     const int q = (kc0 >> 3) + ch;
     const int tap = q >> g.lgC8;
     x_c[j] = (q & ((1 << g.lgC8) - 1)) << 3;
@@ -369,31 +392,70 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(Gather g, const bf16_t
   }
   const int hw = g.Ho * g.Wo;
 
-  f32x4_t acc[COT][4];
+  f32x4_t acc[COT][XT];
 #pragma unroll
   for (int a = 0; a < COT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < XT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---- single-source cursor state
+  constexpr unsigned OOB = 0x80000000u;
+  int cn[IPW], chh[IPW], cww[IPW], cm[IPW], th[IPW], tw[IPW];
+  unsigned yoff[IPW];
+  if constexpr (!CAT) {
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      cm[j] = s_begin * WG_BP + (wave * IPW + j) * 4 + lr;
+      int rem;
+      fast_divmod(cm[j], hw, g.rhw, cn[j], rem);
+      fast_divmod(rem, g.Wo, g.rw, chh[j], cww[j]);
+      th[j] = x_tr[j] - g.pad_h;
+      tw[j] = x_ts[j] - g.pad_w;
+      yoff[j] = ((unsigned)cm[j] * (unsigned)ldy + (unsigned)y_c[j]) * 2u;
+    }
+  }
+  const unsigned ystep = (unsigned)(WG_BP * ldy * 2);
 
   auto issue_stage = [&](int st, int buf) {
-    char* sX = smem + buf * 2 * IMG + wave * 4096;
+    char* sX = smem + buf * 2 * IMG + wave * (IPW * 1024);
     char* sY = sX + IMG;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = st * WG_BP + (wave * 4 + j) * 4 + lr;
-      const bf16_t* px = reinterpret_cast<const bf16_t*>(&g_zero16);
-      const bf16_t* py = px;
-      if (m < g.M) {
-        int n, rem, ho, wo;
-        fast_divmod(m, hw, g.rhw, n, rem);
-        fast_divmod(rem, g.Wo, g.rw, ho, wo);
-        RowInfo r;
-        r.n = n; r.hb = ho * g.smul - g.pad_h; r.wb = wo * g.smul - g.pad_w;
-        px = gather_addr(g, r, x_tr[j], x_ts[j], x_c[j], x_kv[j]);
-        if (y_cv[j]) py = dY + (size_t)m * ldy + y_c[j];
+    for (int j = 0; j < IPW; ++j) {
+      if constexpr (!CAT) {
+        const bool inm = cm[j] < g.M;
+        const int hn = (int)__umul24((unsigned)chh[j], (unsigned)g.smul) + th[j];
+        const int wn = (int)__umul24((unsigned)cww[j], (unsigned)g.smul) + tw[j];
+        const bool ok = inm & x_kv[j] & ((unsigned)hn < (unsigned)g.Hs) & ((unsigned)wn < (unsigned)g.Ws);
+        const unsigned pix = mad24(mad24((unsigned)cn[j], (unsigned)g.Hs, (unsigned)hn), (unsigned)g.Ws, (unsigned)wn);
+        const unsigned xo = mad24(pix, (unsigned)g.C1, (unsigned)x_c[j]) * 2u;
+        buffer_load_lds16(g.src1, ws.x_bytes, sX + j * 1024, ok ? xo : OOB);
+        buffer_load_lds16(dY, ws.y_bytes, sY + j * 1024, (inm & y_cv[j]) ? yoff[j] : OOB);
+        // advance the cursor by 64 pixels
+        cm[j] += WG_BP;
+        yoff[j] += ystep;
+        const int w2 = cww[j] + ws.dw;
+        const int cw = w2 >= g.Wo;
+        cww[j] = w2 - (cw ? g.Wo : 0);
+        const int h2 = chh[j] + ws.dh + cw;
+        const int chc = h2 >= g.Ho;
+        chh[j] = h2 - (chc ? g.Ho : 0);
+        cn[j] += ws.dn + chc;
+      } else {
+        const int m = st * WG_BP + (wave * IPW + j) * 4 + lr;
+        const bf16_t* px = reinterpret_cast<const bf16_t*>(&g_zero16);
+        const bf16_t* py = px;
+        if (m < g.M) {
+          int n, rem, ho, wo;
+          fast_divmod(m, hw, g.rhw, n, rem);
+          fast_divmod(rem, g.Wo, g.rw, ho, wo);
+          RowInfo r;
+          r.n = n; r.hb = ho * g.smul - g.pad_h; r.wb = wo * g.smul - g.pad_w;
+          px = gather_addr(g, r, x_tr[j], x_ts[j], x_c[j], x_kv[j]);
+          if (y_cv[j]) py = dY + (size_t)m * ldy + y_c[j];
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(sX + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)py, (lptr_t)(sY + j * 1024), 16, 0, 0);
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(sX + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)py, (lptr_t)(sY + j * 1024), 16, 0, 0);
     }
   };
   auto compute_stage = [&](int buf) {
@@ -401,15 +463,15 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(Gather g, const bf16_t
     const char* sY = sX + IMG;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t yf[COT], xf[4];
+      bf16x8_t yf[COT], xf[XT];
 #pragma unroll
       for (int a = 0; a < COT; ++a) yf[a] = tr_frag(sY, ks * 32, wr * (BCO / 2) + a * 16, lane);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) xf[b] = tr_frag(sX, ks * 32, wc * 64 + b * 16, lane);
+      for (int b = 0; b < XT; ++b) xf[b] = tr_frag(sX, ks * 32, wc * (XT * 16) + b * 16, lane);
 #pragma unroll
       for (int a = 0; a < COT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < XT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
     }
   };
 
@@ -427,16 +489,52 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(Gather g, const bf16_t
 #pragma unroll
   for (int a = 0; a < COT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int kc = kc0 + wc * 64 + b * 16 + (lane & 15);
+    for (int b = 0; b < XT; ++b) {
+      const int kc = kc0 + wc * (XT * 16) + b * 16 + (lane & 15);
       if (kc < g.Kg) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int co = co0 + wr * (BCO / 2) + a * 16 + (lane >> 4) * 4 + j;
-          if (co < Kout) atomicAdd(dW + (size_t)co * g.Kg + kc, acc[a][b][j]);
+          if (co < Kout) {
+            if (ws.slab) dW[(size_t)blockIdx.z * (size_t)ws.slab + (size_t)co * g.Kg + kc] = acc[a][b][j];
+            else         atomicAdd(dW + (size_t)co * g.Kg + kc, acc[a][b][j]);
+          }
         }
       }
     }
+}
+
+// dW[i] (+)= sum over the split slabs: 256 threads = 64 float4 columns x 4 slab groups (coalesced 1 KiB rows, 4-deep unrolled loads),
+// the groups meet in LDS.  Plain stores + this pass replace the float atomics of the one-pass kernel, which had become 44 % of the
+// weight-gradient time (~0.47 G lane-atomics/us device-wide, while the same bytes as plain stores are nearly free).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restrict__ part, int nslab, long long slab4, float4* __restrict__ dW,
+                                                           int n4, int accumulate) {
+  __shared__ float4 red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p = part + i;
+    int z = grp;
+    for (; z + 12 < nslab; z += 16) {
+      const float4 a = p[(size_t)z * slab4], b = p[(size_t)(z + 4) * slab4], c = p[(size_t)(z + 8) * slab4], d = p[(size_t)(z + 12) * slab4];
+      s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+      s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; z < nslab; z += 4) {
+      const float4 a = p[(size_t)z * slab4];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+  }
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && i < n4) {
+    float4 r = red[0][col];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { r.x += red[k][col].x; r.y += red[k][col].y; r.z += red[k][col].z; r.w += red[k][col].w; }
+    if (accumulate) { const float4 o = dW[i]; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+    dW[i] = r;
+  }
 }
 
 // [Cout][RS][Cin] -> [Cin][RS flipped][Cout], 32x32 tiles through LDS.
@@ -624,36 +722,99 @@ extern "C" int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, con
   return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate, nullptr, nullptr, p->Cin, (hipStream_t)stream);
 }
 
-extern "C" int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
-                                 int split_k, void* stream) {
+namespace {
+struct WgradPlan { Gather g; int bco, tiles_k, tiles_c, split_k, sps; };
+
+// split-K plan: at most `target` workgroups (2 per CU: 64 KiB of LDS each) so that the whole grid is resident in one round -- one
+// workgroup more than the slots costs a second, almost empty round -- and at least 8 pixel-steps per workgroup
+int plan_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, int split_k, int target, WgradPlan* pl) {
   int rc = check_problem(p);
   if (rc) return rc;
-  YOLO_CHECK_ARG(src1 && dy && dw, "null pointer");
   YOLO_CHECK_ARG(p->C0 == 0 || src0, "C0 > 0 needs src0");
-  Gather g = fwd_gather(p, src0, src1);
-  YOLO_CHECK_ARG(g.M < (1 << 24), "wgrad row decode needs N*Ho*Wo < 2^24");
-  const int bco = (p->Cout % 128 == 0) ? 128 : 64;
-  const int tiles_k = (g.Kg + WG_BKC - 1) / WG_BKC;
-  const int tiles_c = (p->Cout + bco - 1) / bco;
-  const int nsteps = (g.M + WG_BP - 1) / WG_BP;
-  if (split_k <= 0) {  // aim at ~2 workgroups per CU (measured best of 256..1536), at least 8 pixel-steps per workgroup
-    split_k = (512 + tiles_k * tiles_c - 1) / (tiles_k * tiles_c);
+  pl->g = fwd_gather(p, src0, src1);
+  YOLO_CHECK_ARG(pl->g.M < (1 << 24), "wgrad row decode needs N*Ho*Wo < 2^24");
+  pl->bco = (p->Cout % 128 == 0) ? 128 : 64;
+  pl->tiles_k = (pl->g.Kg + WG_BKC - 1) / WG_BKC;
+  pl->tiles_c = (p->Cout + pl->bco - 1) / pl->bco;
+  const int nsteps = (pl->g.M + WG_BP - 1) / WG_BP;
+  if (split_k <= 0) {
+    split_k = target / (pl->tiles_k * pl->tiles_c);
     const int max_split = (nsteps + 7) / 8;
     if (split_k > max_split) split_k = max_split;
     if (split_k < 1) split_k = 1;
   }
   if (split_k > nsteps) split_k = nsteps;
-  const int sps = (nsteps + split_k - 1) / split_k;
-  split_k = (nsteps + sps - 1) / sps;
-  YOLO_CHECK_ARG(split_k <= 65535, "split_k too large");
+  pl->sps = (nsteps + split_k - 1) / split_k;
+  pl->split_k = (nsteps + pl->sps - 1) / pl->sps;     // every z owns at least one step
+  YOLO_CHECK_ARG(pl->split_k <= 65535, "split_k too large");
+  return YOLO_OK;
+}
+
+// slab = 0: float atomics into out; slab > 0: split z stores its partial tile to out + z * slab
+void launch_wgrad(const yolo_conv_problem* p, const WgradPlan& pl, const void* dy, float* out, long long slab, hipStream_t stream) {
+  const Gather& g = pl.g;
   const size_t lds = 2 * 2 * WG_BP * 256;
-  const float rhw = 1.0f / (float)(p->Ho * p->Wo), rw = 1.0f / (float)p->Wo;
-  if (bco == 128)
-    hipLaunchKernelGGL(igemm_wgrad_kernel<128>, dim3(tiles_k, tiles_c, split_k), dim3(256), lds, (hipStream_t)stream, g, (const bf16_t*)dy,
-                       p->Cout, dw, p->Cout, sps, rhw, rw);
-  else
-    hipLaunchKernelGGL(igemm_wgrad_kernel<64>, dim3(tiles_k, tiles_c, split_k), dim3(256), lds, (hipStream_t)stream, g, (const bf16_t*)dy,
-                       p->Cout, dw, p->Cout, sps, rhw, rw);
+  // 64 pixels = dn images + dh rows + dw columns of the output grid
+  WgradStep ws;
+  const int hw = p->Ho * p->Wo;
+  ws.dn = WG_BP / hw;
+  ws.dh = (WG_BP % hw) / p->Wo;
+  ws.dw = (WG_BP % hw) % p->Wo;
+  ws.slab = slab;
+  const size_t xb = (size_t)p->N * p->H * p->W * (size_t)(p->Cin - p->C0) * 2, yb = (size_t)g.M * p->Cout * 2;
+  const bool cat = p->C0 > 0 || xb >= (1ull << 31) || yb >= (1ull << 31) || (size_t)p->N * p->H * p->W >= (1u << 24);
+  ws.x_bytes = cat ? 0u : (unsigned)xb;
+  ws.y_bytes = cat ? 0u : (unsigned)yb;
+  const dim3 grid(pl.tiles_k, pl.tiles_c, pl.split_k);
+#define YOLO_WGRAD_LAUNCH(BCO_, CAT_)                                                                                          \
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_, 8, CAT_>), grid, dim3(512), lds, stream, g, (const bf16_t*)dy, p->Cout, out, p->Cout, \
+                     pl.sps, ws)
+  if (pl.bco == 128) { if (cat) YOLO_WGRAD_LAUNCH(128, true); else YOLO_WGRAD_LAUNCH(128, false); }
+  else               { if (cat) YOLO_WGRAD_LAUNCH(64, true);  else YOLO_WGRAD_LAUNCH(64, false); }
+#undef YOLO_WGRAD_LAUNCH
+}
+
+// workgroups aimed at by the two-phase path: 1.5 per CU measured best on the whole step (256 / 384 / 512 tried: fewer slabs to sum
+// and less competition with the main stream's kernels outweigh the shorter pixel ranges of 512)
+constexpr int kWgradTarget = 384;
+}  // namespace
+
+extern "C" int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
+                                 int split_k, void* stream) {
+  YOLO_CHECK_ARG(p && src1 && dy && dw, "null pointer");
+  WgradPlan pl;
+  int rc = plan_wgrad(p, src0, src1, split_k, 384, &pl);
+  if (rc) return rc;
+  launch_wgrad(p, pl, dy, dw, 0, (hipStream_t)stream);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" size_t yolo_conv2d_wgrad_workspace_bytes(const yolo_conv_problem* p) {
+  WgradPlan pl;
+  static const char dummy = 0;
+  if (!p || plan_wgrad(p, &dummy, &dummy, 0, kWgradTarget, &pl)) return 0;
+  return pl.split_k > 1 ? (size_t)pl.split_k * (size_t)p->Cout * (size_t)pl.g.Kg * sizeof(float) : 0;
+}
+
+extern "C" int yolo_conv2d_wgrad_reduce(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
+                                        void* workspace, size_t workspace_bytes, int accumulate, void* stream) {
+  YOLO_CHECK_ARG(p && src1 && dy && dw, "null pointer");
+  WgradPlan pl;
+  int rc = plan_wgrad(p, src0, src1, 0, kWgradTarget, &pl);
+  if (rc) return rc;
+  const size_t n = (size_t)p->Cout * (size_t)pl.g.Kg;
+  if (pl.split_k == 1) {                              // one workgroup per tile: straight into dw (plain stores, or atomics to add)
+    launch_wgrad(p, pl, dy, dw, accumulate ? 0 : (long long)n, (hipStream_t)stream);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+  }
+  YOLO_CHECK_ARG(workspace && workspace_bytes >= (size_t)pl.split_k * n * sizeof(float), "workspace too small (yolo_conv2d_wgrad_workspace_bytes)");
+  YOLO_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0, "dw / workspace must be 16-byte aligned");
+  launch_wgrad(p, pl, dy, (float*)workspace, (long long)n, (hipStream_t)stream);
+  const int n4 = (int)(n / 4);                         // Cin % 8 == 0
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float4*)workspace, pl.split_k,
+                     (long long)(n / 4), (float4*)dw, n4, accumulate);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

@@ -358,6 +358,9 @@ class Graph(object):
                 op.dg_off = n_dg
                 n_dg += _round_up(op.y.wp.numel, SLOT)
         self.w_dgrad = torch.zeros(max(n_dg, SLOT), dtype=torch.bfloat16, device=dev)
+        # one slab workspace for the two-phase weight gradients (they run back to back on one stream)
+        ws_bytes = max([ops.conv2d_wgrad_workspace_bytes(op.y.p) for op in self.tape if isinstance(op, ConvOp)] + [16])
+        self.wgrad_ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
         for op in self.tape:
             op.bind()
         self.fwd = [lambda: ops.pack_input(self.images, self.input_val.buf, N * H * W, C)]
@@ -487,7 +490,7 @@ class ConvOp(object):
     def _wgrad(self):
         y = self.y
         s0 = None if self.src0 is None else self.src0.buf
-        ops.conv2d_wgrad(y.p, self.src1.buf, y.dy, self.dw, src0=s0)
+        ops.conv2d_wgrad_reduce(y.p, self.src1.buf, y.dy, self.dw, self.g.wgrad_ws, src0=s0)
         if self.dbias is not None:
             C = y.shape[3]
             ops.bn_stats(y.dy, y.M, C, self.bpart)

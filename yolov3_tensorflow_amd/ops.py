@@ -60,6 +60,17 @@ def conv2d_wgrad(p, src1, dy, dw, src0=None, split_k=0):
     check(_lib.load().yolo_conv2d_wgrad(C.byref(p), _p(src0), _p(src1), _p(dy), _p(dw), split_k, _stream()), 'yolo_conv2d_wgrad')
 
 
+def conv2d_wgrad_workspace_bytes(p):
+    return int(_lib.load().yolo_conv2d_wgrad_workspace_bytes(C.byref(p)))
+
+
+def conv2d_wgrad_reduce(p, src1, dy, dw, workspace, src0=None, accumulate=False):
+    """two-phase weight gradient (split slabs -> workspace, then one summing pass): no atomics, dw is overwritten unless accumulate"""
+    check(_lib.load().yolo_conv2d_wgrad_reduce(C.byref(p), _p(src0), _p(src1), _p(dy), _p(dw), _p(workspace),
+                                               workspace.numel() * workspace.element_size(), int(accumulate), _stream()),
+          'yolo_conv2d_wgrad_reduce')
+
+
 def repack_dgrad_weights(w_fwd, w_dgrad, Cout, R, S, Cin):
     check(_lib.load().yolo_repack_dgrad_weights(_p(w_fwd), _p(w_dgrad), Cout, R, S, Cin, _stream()), 'yolo_repack_dgrad_weights')
 
