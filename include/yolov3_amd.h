@@ -52,6 +52,10 @@ typedef struct {
  * writes per-channel partial sums / sums of squares of the bf16-rounded outputs: arrays [stat_rows][Cout] where
  * stat_rows = yolo_conv2d_stat_rows(p) (reduced later by yolo_bn_finalize). */
 int yolo_conv2d_stat_rows(const yolo_conv_problem* p);
+/* Test / benchmark hook: override a kernel-selection heuristic.  "strip_bm": -1 auto (default), 0 never use the LDS-resident strip
+ * kernel for 3x3 stride-1 convolutions, 64 / 128 / 256 force its pixel tile; "strip_bn": 0 auto, 64 / 128.  Changes
+ * yolo_conv2d_stat_rows() accordingly: set it before sizing statistics buffers. */
+int yolo_set_tuning(const char* name, int value);
 int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd, const float* bias,
                     void* y, int y_is_f32, float* stat_sum, float* stat_sq, void* stream);
 /* dx[N,H,W,Cin] (=|+=) conv_transpose(dy[N,Ho,Wo,Cout], w).  Cin must be a multiple of 64.  accumulate != 0 adds into dx. */

@@ -44,6 +44,13 @@ CONV_CASES = [
     (2, 10, 14, 64, 128, 1, 2, 'valid'),    # NIN shortcut
     (2, 16, 16, 8, 64, 3, 2, 'same'),       # stem (RGB padded to 8 channels), K = 72 not a multiple of 64
     (1, 7, 7, 512, 256, 3, 1, 'same'),
+    # large enough for the LDS-resident strip kernel (3x3 / stride 1): 128- and 256-pixel tiles, 64 / 128 wide, strips that span several
+    # images (13 x 13), two 64-channel slices, non-square maps
+    (128, 13, 13, 64, 512, 3, 1, 'same'),
+    (5, 100, 100, 64, 64, 3, 1, 'same'),
+    (4, 160, 160, 64, 64, 3, 1, 'same'),
+    (3, 96, 96, 128, 512, 3, 1, 'same'),
+    (40, 52, 20, 64, 256, 3, 1, 'same'),
 ]
 
 
@@ -118,6 +125,49 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
         torch.testing.assert_close(dx.float().cpu(), xr.grad, rtol=1e-2, atol=1e-2)
         ops.conv2d_dgrad(p, dyd, w_dg, dx, accumulate=True)        # fan-in accumulation: dx += dgrad
         torch.testing.assert_close(dx.float().cpu(), 2 * xr.grad, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('bm,bn', [(64, 64), (64, 128), (128, 64), (128, 128), (256, 64), (256, 128)])
+def test_strip_conv_variants_match_implicit_gemm(dev, bm, bn):
+    """every tile variant of the LDS-resident strip kernel (3x3 / stride 1) against the implicit-GEMM kernel on the same inputs: forward with
+    BatchNorm partial statistics, data gradient with fan-in accumulation; 3 images of 21 x 19 put image boundaries, row wraps and the
+    ragged last tile inside the strips, 128 input channels = two 64-channel slices"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(99)
+    N, H, W, Cin, Cout = 3, 21, 19, 128, 256
+    x = bf(torch.randn(N, H, W, Cin, generator=g)).to(dev)
+    w = bf(torch.randn(Cout, 3, 3, Cin, generator=g) * 0.03).to(dev)
+    dy = bf(torch.randn(N, H, W, Cout, generator=g)).to(dev)
+    p = ops.conv_problem(N, H, W, Cin, Cout, 3, 1, 'same')
+    w_dg = torch.empty(Cin, 3, 3, Cout, dtype=torch.bfloat16, device=dev)
+    ops.repack_dgrad_weights(w, w_dg, Cout, 3, 3, Cin)
+
+    def run():
+        rows = ops.conv2d_stat_rows(p)
+        y = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=dev)
+        ss, sq = torch.zeros(rows, Cout, device=dev), torch.zeros(rows, Cout, device=dev)
+        ops.conv2d_fwd(p, x, w, y, stat_sum=ss, stat_sq=sq)
+        dx = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
+        ops.conv2d_dgrad(p, dy, w_dg, dx)
+        ops.conv2d_dgrad(p, dy, w_dg, dx, accumulate=True)
+        torch.cuda.synchronize()
+        return y.float().cpu(), ss.sum(0).cpu(), sq.sum(0).cpu(), dx.float().cpu()
+
+    try:
+        ops.set_tuning('strip_bm', 0)
+        ref = run()
+        ops.set_tuning('strip_bm', bm)
+        ops.set_tuning('strip_bn', bn)
+        assert ops.conv2d_stat_rows(p) == (N * H * W + bm - 1) // bm
+        got = run()
+    finally:
+        ops.set_tuning('strip_bm', -1)
+        ops.set_tuning('strip_bn', 0)
+    # same products, different float32 summation order, one bf16 rounding: at most 1 bf16 ulp apart
+    torch.testing.assert_close(got[0], ref[0], rtol=2 ** -7, atol=1e-3)
+    torch.testing.assert_close(got[1], ref[1], rtol=1e-3, atol=0.5)
+    torch.testing.assert_close(got[2], ref[2], rtol=1e-3, atol=0.5)
+    torch.testing.assert_close(got[3], ref[3], rtol=2 ** -6, atol=2e-3)
 
 
 def test_conv_fused_upsample_concat(dev):

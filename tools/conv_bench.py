@@ -16,6 +16,9 @@ LAYERS = {   # name: (H, W, Cin, Cout, k, stride, padding)
     '512': (13, 13, 512, 512, 3, 1, 'same'),
     '128s2': (104, 104, 64, 128, 3, 2, 'same'),
     '1x1': (52, 52, 256, 128, 1, 1, 'same'),
+    'h13': (13, 13, 512, 256, 3, 1, 'same'),
+    'h26': (26, 26, 256, 512, 3, 1, 'same'),
+    'h52': (52, 52, 128, 256, 3, 1, 'same'),
 }
 
 
@@ -28,6 +31,9 @@ def main():
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     N = a.batch
+    if os.environ.get('YOLO_STRIP'):
+        ops.set_tuning('strip_bm', int(os.environ['YOLO_STRIP']))
+        ops.set_tuning('strip_bn', int(os.environ.get('YOLO_STRIP_BN', '0')))
     for name in a.layers.split(','):
         H, W, Cin, Cout, k, s, pad = LAYERS[name]
         p = ops.conv_problem(N, H, W, Cin, Cout, k, s, pad)

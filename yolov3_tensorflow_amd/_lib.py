@@ -40,6 +40,7 @@ SIGNATURES = {
     'yolo_abi_version': (I, []),
     'yolo_last_error': (C.c_char_p, []),
     'yolo_conv2d_stat_rows': (I, [CP]),
+    'yolo_set_tuning': (I, [C.c_char_p, I]),
     'yolo_conv2d_fwd': (I, [CP, P, P, P, P, P, I, P, P, P]),
     'yolo_conv2d_dgrad': (I, [CP, P, P, P, I, P]),
     'yolo_conv2d_wgrad': (I, [CP, P, P, P, P, I, P]),

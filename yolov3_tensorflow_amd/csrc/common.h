@@ -50,6 +50,16 @@ __device__ __forceinline__ uint4 pack_bf8(const float* f) {
 }
 
 // ---- wave / block reductions (64-wide wavefronts) ----
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: quad butterflies, then half-row and row mirrors
+// (each step is one v_add_f32 with a DPP modifier -- no LDS traffic, unlike __shfl_xor -> ds_bpermute_b32)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

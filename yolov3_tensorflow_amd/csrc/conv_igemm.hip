@@ -15,6 +15,7 @@
 //                    so fragments are read with ds_read_b64_tr_b16 (hardware transpose); split over pixel ranges,
 //                    fp32 atomics into dW.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -96,6 +97,113 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 constexpr int BK = 64;  // K elements per stage
+
+// Tile epilogue shared by the conv kernels: lane holds channels co..co+3 (rows of D) of pixel (column of D); acc[a][b] = channel tile a x
+// pixel tile b of this wave (wave grid WM pixels x WN channels).  bf16 outputs are staged through LDS (the operand buffers are free by
+// then), optional BatchNorm partial statistics go to one row per pixel tile.
+template <int BM, int BN, int NW, int WM, int WN, int PT, int CT, bool OUT_F32>
+__device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem, int M, int m0, int n0, int tile_m, const float* __restrict__ bias,
+                                              void* __restrict__ Yv, int ldy, int accumulate, float* __restrict__ stat_sum,
+                                              float* __restrict__ stat_sq, int Kout, int tid, int lane, int wm, int wn) {
+  const int cq = (lane >> 4) * 4;
+  float ssum[CT][4], ssq[CT][4];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
+
+  if constexpr (OUT_F32) {   // float32 logits (+ bias): 16 bytes per lane, written straight from the accumulators
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      const int m = m0 + wm * (PT * 16) + b * 16 + (lane & 15);
+      if (m < M) {
+#pragma unroll
+        for (int a = 0; a < CT; ++a) {
+          const int co = n0 + wn * (CT * 16) + a * 16 + cq;
+          float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+          if (bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bias[co + j];
+          }
+          float* y = reinterpret_cast<float*>(Yv) + (size_t)m * ldy + co;
+          if (accumulate) { float4 o = *reinterpret_cast<float4*>(y); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+          *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  } else {
+    // bf16 activations: the tile is transposed through LDS (free now) so that every store instruction writes whole 128/256-byte
+    // NHWC rows -- straight from the accumulators each instruction wrote 16 scattered 32-byte segments, which cost more than the
+    // MFMAs of the whole tile on the 64-channel layers (ablation: 39 of 70 us)
+    constexpr int OLD = BN * 2 + 16;                  // LDS row stride in bytes (16-byte pad: conflict-free 8-byte writes)
+    __syncthreads();                                  // every wave is done with the operand ring
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      const int pl = wm * (PT * 16) + b * 16 + (lane & 15);
+#pragma unroll
+      for (int a = 0; a < CT; ++a) {
+        const int cl = wn * (CT * 16) + a * 16 + cq;
+        uint2 o;
+        o.x = pack_bf2(acc[a][b][0], acc[a][b][1]);
+        o.y = pack_bf2(acc[a][b][2], acc[a][b][3]);
+        *reinterpret_cast<uint2*>(smem + pl * OLD + cl * 2) = o;
+        if (stat_sum && !accumulate && m0 + pl < M) {   // statistics of the values as stored (bf16-rounded)
+          const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
+          const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+          ssum[a][0] += r0; ssum[a][1] += r1; ssum[a][2] += r2; ssum[a][3] += r3;
+          ssq[a][0] += r0 * r0; ssq[a][1] += r1 * r1; ssq[a][2] += r2 * r2; ssq[a][3] += r3 * r3;
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                       // 16-byte chunks per row
+    bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
+    for (int i = tid; i < BM * CPR; i += NW * 64) {
+      const int row = i / CPR, ch = i - row * CPR;
+      const int m = m0 + row;
+      if (m < M) {
+        uint4 v = *reinterpret_cast<const uint4*>(smem + row * OLD + ch * 16);
+        bf16_t* yp = Y + (size_t)m * ldy + n0 + ch * 8;
+        if (accumulate) {                             // gradient fan-in: y += tile (float32 add, one rounding)
+          float a8[8], b8[8];
+          unpack_bf8(v, a8);
+          unpack_bf8(*reinterpret_cast<const uint4*>(yp), b8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a8[j] += b8[j];
+          v = pack_bf8(a8);
+        }
+        *reinterpret_cast<uint4*>(yp) = v;
+      }
+    }
+  }
+
+  if (stat_sum) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
+    __syncthreads();                                  // every wave is done with the staged output tile
+    float* red = reinterpret_cast<float*>(smem);      // [2][WM][BN]
+#pragma unroll
+    for (int a = 0; a < CT; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = ssum[a][j], q = ssq[a][j];
+        s = row16_sum(s);
+        q = row16_sum(q);
+        if ((lane & 15) == 0) {
+          const int cl = wn * (CT * 16) + a * 16 + cq + j;
+          red[wm * BN + cl] = s;
+          red[(WM + wm) * BN + cl] = q;
+        }
+      }
+    __syncthreads();
+    for (int cl = tid; cl < BN; cl += NW * 64) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { s += red[w * BN + cl]; q += red[(WM + w) * BN + cl]; }
+      stat_sum[(size_t)tile_m * Kout + n0 + cl] = s;
+      stat_sq[(size_t)tile_m * Kout + n0 + cl] = q;
+    }
+  }
+}
+
 
 // Forward / data-gradient implicit GEMM.  BM pixels x BN channels per 256-thread workgroup; a 3-stage LDS ring filled by LDS-DMA
 // (global_load_lds_dwordx4: 16 B per lane, no VGPR staging), counted vmcnt so that one stage stays in flight across the single raw
@@ -222,104 +330,148 @@ __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16
     compute_stage(kt % NSTAGE);
   }
 
-  // ---- epilogue: lane holds channels co..co+3 (rows of D) of pixel (column of D) ----
-  const int cq = (lane >> 4) * 4;
-  float ssum[CT][4], ssq[CT][4];
-#pragma unroll
-  for (int a = 0; a < CT; ++a)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
+  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, OUT_F32>(acc, smem, g.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane, wm, wn);
+}
 
-  if constexpr (OUT_F32) {   // float32 logits (+ bias): 16 bytes per lane, written straight from the accumulators
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / SAME convolution with the input strip resident in LDS
+// ------------------------------------------------------------------------------------------------------------------
+// The implicit-GEMM kernel above re-gathers the pixel operand for each of the 9 taps, and on the large feature maps it runs at the
+// L2 -> LDS gather rate (~14 TB/s over all CUs at 64 FLOP/B for 128 x 128 tiles), not at the MFMA rate.  Here a workgroup owns BM
+// consecutive pixels (linear NHW index) x BN output channels and, per 64-channel slice, loads the strip of pixels
+// [m0 - (W+1), m0 + BM + (W+1)) ONCE; tap (tr, ts) of pixel p is strip row p + tr*W + ts, so the 9 taps are 9 shifted reads of the same
+// LDS image (the XOR swizzle chunk ^= row & 7 is conflict-free for ds_read_b128 at every row alignment).  Taps that fall off the image
+// (SAME padding, row wrap, image boundary inside the strip) are redirected lane by lane to a zero row.  Only the weight tile
+// (BN x 64 per tap and slice) streams through a 2-stage ring.  L2 -> LDS bytes per tile drop 2.6-3.3x for 256-pixel tiles.
+struct StripArgs {
+  const bf16_t* src; unsigned src_bytes;   // NHWC activations (or dY for the stride-1 data gradient)
+  const bf16_t* wt;  unsigned wt_bytes;    // [Kout][9][C]
+  int H, W, C, M, Kg;                      // M = N*H*W, Kg = 9*C
+  int E8;                                  // strip rows, multiple of 8 (>= BM + 2W + 2)
+  float rhw, rw;
+};
+
+template <int BM, int BN, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, const float* __restrict__ bias, void* __restrict__ Yv, int ldy,
+                                                            int accumulate, float* __restrict__ stat_sum, float* __restrict__ stat_sq,
+                                                            int Kout, int tiles_n) {
+  constexpr int WN = (BN == 128) ? 2 : 1;
+  constexpr int WM = NW / WN;
+  constexpr int PT = BM / WM / 16;
+  constexpr int CT = BN / WN / 16;
+  constexpr int B_INSTR = BN / (8 * NW);   // weight LDS-DMA instructions per wave per k-step (8 rows x 128 B each)
+  constexpr int W_STAGE = BN * 128;
+  static_assert(B_INSTR >= 1, "tile too small for the wave count");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sStrip = smem;
+  char* const sZero = smem + a.E8 * 128;
+  char* const sRing = sZero + 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (tid < 8) *reinterpret_cast<uint4*>(sZero + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+  // LDS-DMA lane geometry (both images): lane -> row (lane >> 3) of the instruction's 8 rows, slot lane & 7 holds chunk slot ^ row
+  const int lrow = lane >> 3;
+  const int cchunk = (lane & 7) ^ lrow;
+  // strip: instruction i covers strip rows 8i .. 8i+7 = pixels m0 - (W+1) + 8i + lrow; out-of-tensor pixels are out of the buffer
+  // range (negative offsets wrap above 2^31) and arrive as zeros
+  const int strip_off0 = ((m0 - (a.W + 1) + wave * 8 + lrow) * a.C + cchunk * 8) * 2;
+  const int strip_step = NW * 8 * a.C * 2;
+  const int n_strip_instr = a.E8 >> 3;
+  unsigned wbase[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) wbase[j] = (unsigned)(((n0 + (wave * B_INSTR + j) * 8 + lrow) * a.Kg + cchunk * 8) * 2);
+
+  // per pixel tile of this wave: tile-local pixel index and the validity of its 3 tap rows / 3 tap columns
+  int prow[PT];
+  unsigned pmask[PT];
+#pragma unroll
+  for (int b = 0; b < PT; ++b) {
+    prow[b] = wm * (PT * 16) + b * 16 + (lane & 15);
+    const int m = m0 + prow[b];
+    unsigned mk = 0;
+    if (m < a.M) {
+      int n, rem, y, x;
+      fast_divmod(m, a.H * a.W, a.rhw, n, rem);
+      fast_divmod(rem, a.W, a.rw, y, x);
+      mk = (y > 0 ? 1u : 0u) | 2u | (y < a.H - 1 ? 4u : 0u) | (x > 0 ? 8u : 0u) | 16u | (x < a.W - 1 ? 32u : 0u);
+    }
+    pmask[b] = mk;
+  }
+  const int kq = lane >> 4;                 // k group of the MFMA operand layout: channels 8*kq .. +7 of a 32-channel substep
+  const int zero_addr = a.E8 * 128 + kq * 16;
+
+  f32x4_t acc[CT][PT];
+#pragma unroll
+  for (int a_ = 0; a_ < CT; ++a_)
+#pragma unroll
+    for (int b = 0; b < PT; ++b) acc[a_][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = a.C >> 6;
+  const int nk = nchunk * 9;
+
+  auto issue_weights = [&](int cc, int tap, int stage) {
+    char* sB = sRing + stage * W_STAGE + wave * (B_INSTR * 1024);
+    const unsigned koff = (unsigned)((tap * a.C + cc * 64) * 2);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) buffer_load_lds16(a.wt, a.wt_bytes, sB + j * 1024, wbase[j] + koff);
+  };
+  auto issue_strip = [&](int cc) {
+    int off = strip_off0 + cc * 128;
+    for (int i = wave; i < n_strip_instr; i += NW) {
+      buffer_load_lds16(a.src, a.src_bytes, sStrip + i * 1024, (unsigned)off);
+      off += strip_step;
+    }
+  };
+  auto compute = [&](int tr, int ts, int stage) {
+    const char* sB = sRing + stage * W_STAGE;
+    const int toff = tr * a.W + ts;
+    int baddr[PT];
 #pragma unroll
     for (int b = 0; b < PT; ++b) {
-      const int m = m0 + wm * (PT * 16) + b * 16 + (lane & 15);
-      if (m < g.M) {
-#pragma unroll
-        for (int a = 0; a < CT; ++a) {
-          const int co = n0 + wn * (CT * 16) + a * 16 + cq;
-          float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-          if (bias) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += bias[co + j];
-          }
-          float* y = reinterpret_cast<float*>(Yv) + (size_t)m * ldy + co;
-          if (accumulate) { float4 o = *reinterpret_cast<float4*>(y); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-          *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
+      const int row = prow[b] + toff;
+      const bool ok = ((pmask[b] >> tr) & (pmask[b] >> (3 + ts)) & 1u) != 0u;
+      baddr[b] = ok ? row * 128 + ((kq ^ (row & 7)) << 4) : zero_addr;
     }
-  } else {
-    // bf16 activations: the tile is transposed through LDS (free now) so that every store instruction writes whole 128/256-byte
-    // NHWC rows -- straight from the accumulators each instruction wrote 16 scattered 32-byte segments, which cost more than the
-    // MFMAs of the whole tile on the 64-channel layers (ablation: 39 of 70 us)
-    constexpr int OLD = BN * 2 + 16;                  // LDS row stride in bytes (16-byte pad: conflict-free 8-byte writes)
-    __syncthreads();                                  // every wave is done with the operand ring
 #pragma unroll
-    for (int b = 0; b < PT; ++b) {
-      const int pl = wm * (PT * 16) + b * 16 + (lane & 15);
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t wf[CT], pf[PT];
+      const int ch = ks * 4 + kq;
 #pragma unroll
-      for (int a = 0; a < CT; ++a) {
-        const int cl = wn * (CT * 16) + a * 16 + cq;
-        uint2 o;
-        o.x = pack_bf2(acc[a][b][0], acc[a][b][1]);
-        o.y = pack_bf2(acc[a][b][2], acc[a][b][3]);
-        *reinterpret_cast<uint2*>(smem + pl * OLD + cl * 2) = o;
-        if (stat_sum && !accumulate && m0 + pl < g.M) {   // statistics of the values as stored (bf16-rounded)
-          const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
-          const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
-          ssum[a][0] += r0; ssum[a][1] += r1; ssum[a][2] += r2; ssum[a][3] += r3;
-          ssq[a][0] += r0 * r0; ssq[a][1] += r1 * r1; ssq[a][2] += r2 * r2; ssq[a][3] += r3 * r3;
-        }
-      }
+      for (int a_ = 0; a_ < CT; ++a_) wf[a_] = *reinterpret_cast<const bf16x8_t*>(sB + swz(wn * (CT * 16) + a_ * 16 + (lane & 15), ch));
+#pragma unroll
+      for (int b = 0; b < PT; ++b) pf[b] = *reinterpret_cast<const bf16x8_t*>(smem + (baddr[b] ^ (ks << 6)));   // chunk ^ 4 (zero row: still zeros)
+#pragma unroll
+      for (int a_ = 0; a_ < CT; ++a_)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) acc[a_][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a_], pf[b], acc[a_][b], 0, 0, 0);
     }
-    __syncthreads();
-    constexpr int CPR = BN / 8;                       // 16-byte chunks per row
-    bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
-    for (int i = tid; i < BM * CPR; i += NW * 64) {
-      const int row = i / CPR, ch = i - row * CPR;
-      const int m = m0 + row;
-      if (m < g.M) {
-        uint4 v = *reinterpret_cast<const uint4*>(smem + row * OLD + ch * 16);
-        bf16_t* yp = Y + (size_t)m * ldy + n0 + ch * 8;
-        if (accumulate) {                             // gradient fan-in: y += tile (float32 add, one rounding)
-          float a8[8], b8[8];
-          unpack_bf8(v, a8);
-          unpack_bf8(*reinterpret_cast<const uint4*>(yp), b8);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a8[j] += b8[j];
-          v = pack_bf8(a8);
-        }
-        *reinterpret_cast<uint4*>(yp) = v;
-      }
-    }
-  }
+  };
 
-  if (stat_sum) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
-    __syncthreads();                                  // every wave is done with the staged output tile
-    float* red = reinterpret_cast<float*>(smem);      // [2][WM][BN]
-#pragma unroll
-    for (int a = 0; a < CT; ++a)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float s = ssum[a][j], q = ssq[a][j];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if ((lane & 15) == 0) {
-          const int cl = wn * (CT * 16) + a * 16 + cq + j;
-          red[wm * BN + cl] = s;
-          red[(WM + wm) * BN + cl] = q;
+  issue_weights(0, 0, 0);
+  int kk = 0;
+  for (int cc = 0; cc < nchunk; ++cc) {
+    if (cc > 0) __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous slice's strip
+    issue_strip(cc);
+    for (int tr = 0; tr < 3; ++tr)
+      for (int ts = 0; ts < 3; ++ts, ++kk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // strip + weight stage kk visible; weight stage kk-1 no longer read
+        asm volatile("" ::: "memory");
+        if (kk + 1 < nk) {
+          const int t1 = tr * 3 + ts + 1;
+          issue_weights(t1 == 9 ? cc + 1 : cc, t1 == 9 ? 0 : t1, (kk + 1) & 1);
         }
+        compute(tr, ts, kk & 1);
       }
-    __syncthreads();
-    for (int cl = tid; cl < BN; cl += NW * 64) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) { s += red[w * BN + cl]; q += red[(WM + w) * BN + cl]; }
-      stat_sum[(size_t)tile_m * Kout + n0 + cl] = s;
-      stat_sq[(size_t)tile_m * Kout + n0 + cl] = q;
-    }
   }
+  __syncthreads();   // all waves are done with strip / ring before the epilogue reuses the LDS (tile_epilogue syncs only for bf16 outputs)
+  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, false>(acc, smem, a.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane,
+                                                   wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -626,9 +778,61 @@ TileCfg pick_tile(int M, int Kout) {
   if (t.bm == 64 && t.bn == 128 && (long)((M + 63) / 64) * (Kout / 128) < 512) t.bn = 64;
   return t;
 }
-int stat_rows_for(int M, int Kout) {
-  const TileCfg t = pick_tile(M, Kout);
-  return (M + t.bm - 1) / t.bm;      // one partial row per pixel tile
+// strip kernel plan: 0 = not eligible, else the pixel tile BM (and the channel tile through *bnp)
+// tuning overrides (yolo_set_tuning): strip_bm = -1 auto, 0 = never use the strip kernel, 64 / 128 / 256 = force; strip_bn = 0 auto
+int g_strip_bm = -1, g_strip_bn = 0;
+int pick_strip(const Gather& g, int Kout, bool f32, int* bnp = nullptr) {
+  if (f32 || g.den != 1 || g.C0 != 0 || g.S != 3 || g.RS != 9 || g.smul != 1 || g.pad_h != 1 || g.pad_w != 1) return 0;
+  if (g.Hs != g.Ho || g.Ws != g.Wo || g.C1 % 64 != 0 || Kout % 64 != 0) return 0;
+  const size_t nimg = (size_t)g.M / ((size_t)g.Ho * g.Wo);
+  if (nimg * g.Hs * g.Ws * g.C1 * 2 >= (1ull << 31) || (size_t)Kout * g.Kg * 2 >= (1ull << 31)) return 0;
+  const int env = g_strip_bm;
+  if (env == 0) return 0;
+  // measured on the ResNet18-YOLOv3 layers at batch 32 (tools/conv_bench.py): 256-pixel tiles on the widest maps (halo 2W+2 rows per
+  // tile), 128 otherwise, 64 on the 13 x 13 maps; 64-channel tiles (3 workgroups per CU) unless that makes > 2048 workgroups
+  int bm = g.Wo >= 80 ? 256 : (g.M >= 8192 ? 128 : 64);
+  int bn = (Kout % 128 == 0 && (long)((g.M + bm - 1) / bm) * (Kout / 64) > 2048) ? 128 : 64;
+  if (env > 0) {
+    bm = env;
+    if (g_strip_bn == 64 || (g_strip_bn == 128 && Kout % 128 == 0)) bn = g_strip_bn;
+  }
+  if (bm != 64 && bm != 128 && bm != 256) return 0;
+  if (bnp) *bnp = bn;
+  const size_t lds = (size_t)((bm + 2 * g.Wo + 2 + 7) / 8 * 8) * 128 + 128 + 2 * (size_t)bn * 128;
+  if (lds > 160 * 1024) return 0;
+  return bm;
+}
+int stat_rows_for(const Gather& g, int Kout) {
+  const int sb = pick_strip(g, Kout, false);
+  if (sb) return (g.M + sb - 1) / sb;
+  const TileCfg t = pick_tile(g.M, Kout);
+  return (g.M + t.bm - 1) / t.bm;      // one partial row per pixel tile
+}
+
+template <int BM, int BN, int NW>
+int launch_strip(const Gather& g, const void* w, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout, hipStream_t st) {
+  StripArgs a;
+  a.src = g.src1;
+  a.src_bytes = (unsigned)((size_t)g.M / ((size_t)g.Ho * g.Wo) * g.Hs * g.Ws * g.C1 * 2);
+  a.wt = (const bf16_t*)w;
+  a.wt_bytes = (unsigned)((size_t)Kout * g.Kg * 2);
+  a.H = g.Ho; a.W = g.Wo; a.C = g.C1; a.M = g.M; a.Kg = g.Kg;
+  a.E8 = (BM + 2 * g.Wo + 2 + 7) / 8 * 8;
+  a.rhw = g.rhw; a.rw = g.rw;
+  const size_t lds_main = (size_t)a.E8 * 128 + 128 + 2 * (size_t)BN * 128, lds_out = (size_t)BM * (BN * 2 + 16);
+  const size_t lds = lds_main > lds_out ? lds_main : lds_out;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<BM, BN, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
+  hipLaunchKernelGGL((conv3x3_strip_kernel<BM, BN, NW>), dim3(tiles_m * tn), dim3(NW * 64), lds, st, a, nullptr, y, ldy, accumulate, ssum, ssq,
+                     Kout, tn);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
 }
 
 template <int BM, int BN, int NS, bool F32, bool FAST, int NW>
@@ -675,6 +879,16 @@ int launch_tile(const Gather& g, const void* w, const float* bias, void* y, int 
 template <bool F32>
 int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq,
                int Kout, hipStream_t st) {
+  int sbn = 0;
+  if (const int sb = pick_strip(g, Kout, F32, &sbn)) {
+    const bool wide = sbn == 128;
+    if (sb == 64) return wide ? launch_strip<64, 128, 4>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st)
+                              : launch_strip<64, 64, 4>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
+    if (sb == 256) return wide ? launch_strip<256, 128, 8>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st)
+                               : launch_strip<256, 64, 8>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
+    return wide ? launch_strip<128, 128, 8>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st)
+                : launch_strip<128, 64, 4>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
+  }
   const TileCfg t = pick_tile(g.M, Kout);
   if (t.bm == 128 && t.bn == 128) return launch_tile<128, 128, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
   if (t.bm == 128 && t.bn == 64) return launch_tile<128, 64, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
@@ -684,9 +898,19 @@ int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int l
 
 }  // namespace
 
+extern "C" int yolo_set_tuning(const char* name, int value) {
+  YOLO_CHECK_ARG(name != nullptr, "null name");
+  if (!strcmp(name, "strip_bm")) { YOLO_CHECK_ARG(value == -1 || value == 0 || value == 64 || value == 128 || value == 256, "strip_bm"); g_strip_bm = value; }
+  else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
+  else YOLO_CHECK_ARG(false, "unknown tuning name");
+  return YOLO_OK;
+}
+
 extern "C" int yolo_conv2d_stat_rows(const yolo_conv_problem* p) {
   if (!p || p->Cout % 64 != 0 || p->N <= 0 || p->Ho <= 0 || p->Wo <= 0) return YOLO_ERR_INVALID_ARG;
-  return stat_rows_for(p->N * p->Ho * p->Wo, p->Cout);
+  if (check_problem(p)) return YOLO_ERR_INVALID_ARG;
+  static const char dummy = 0;
+  return stat_rows_for(fwd_gather(p, &dummy, &dummy), p->Cout);
 }
 
 extern "C" int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd,

@@ -40,6 +40,11 @@ def pad_channels(c):
     return p
 
 
+def set_tuning(name, value):
+    """test / benchmark hook (yolo_set_tuning): override a kernel-selection heuristic"""
+    check(_lib.load().yolo_set_tuning(name.encode(), int(value)), 'yolo_set_tuning')
+
+
 def conv2d_stat_rows(p):
     r = _lib.load().yolo_conv2d_stat_rows(C.byref(p))
     if r < 0:
