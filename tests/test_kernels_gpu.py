@@ -170,6 +170,39 @@ def test_strip_conv_variants_match_implicit_gemm(dev, bm, bn):
     torch.testing.assert_close(got[3], ref[3], rtol=2 ** -6, atol=2e-3)
 
 
+@pytest.mark.parametrize('shape', [(3, 21, 19, 128, 256), (70, 13, 13, 64, 64), (2, 40, 104, 64, 128), (1, 5, 3, 64, 64)])
+def test_wgrad_strip_matches_generic(dev, shape):
+    """the kernel-row strip weight gradient (3x3 / stride 1) against the generic im2col one: image boundaries and row wraps inside the
+    64-pixel stages (13 x 13), maps wider than a stage (W = 104), a map smaller than the halo (5 x 3), two 64-channel slices, both
+    output-channel tiles, atomics and two-phase modes"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Cin, Cout = shape
+    x = bf(torch.randn(N, H, W, Cin, generator=g)).to(dev)
+    dy = bf(torch.randn(N, H, W, Cout, generator=g)).to(dev)
+    p = ops.conv_problem(N, H, W, Cin, Cout, 3, 1, 'same')
+
+    def run():
+        dw = torch.zeros(Cout, 3, 3, Cin, device=dev)
+        ops.conv2d_wgrad(p, x, dy, dw)
+        ws = torch.empty(max(ops.conv2d_wgrad_workspace_bytes(p), 16) // 4, device=dev)
+        dw2 = torch.empty_like(dw)
+        ops.conv2d_wgrad_reduce(p, x, dy, dw2, ws)
+        torch.cuda.synchronize()
+        return dw.cpu(), dw2.cpu()
+
+    try:
+        ops.set_tuning('wgrad_strip', 0)
+        ref = run()
+        ops.set_tuning('wgrad_strip', 1)
+        got = run()
+    finally:
+        ops.set_tuning('wgrad_strip', 1)
+    scale = ref[1].abs().max().item()
+    for t in got:      # same bf16 products, float32 sums in a different order
+        torch.testing.assert_close(t, ref[1], rtol=1e-4, atol=1e-5 * scale)
+
+
 def test_conv_fused_upsample_concat(dev):
     """1x1 conv over concat(upsample2x(a), b) without materialising the concat (yolov3_detector.py:115-118)"""
     from yolov3_tensorflow_amd import ops

@@ -656,6 +656,190 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(Gather g, const bf
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of 3x3 / stride 1 / SAME convolutions with the three taps of one kernel row sharing one X image
+// ------------------------------------------------------------------------------------------------------------------
+// The generic kernel above gathers X once per tap.  Here a workgroup owns (kernel row tr, 64 input channels cc, BCO output channels):
+// D[co][s][ci] for s = 0..2, and per 64-pixel stage loads the X strip of pixels [m0 + (tr-1)W - 1, +66) ONCE (128-byte rows = the 64
+// channels); tap s of pixel k is strip row k + s, so the three taps are three shifted transposed reads of one LDS image.  The bytes
+// fetched per FLOP drop from 1/64 (128 x 128 tile) to 1/126 (128 x 192), 1/43 -> 1/92 for 64-channel layers.
+//  - vertical validity (y + tr - 1 outside the image, which in the linear strip is the neighbouring image) depends only on the X
+//    pixel's own row: those strip rows are loaded as zeros (buffer range check);
+//  - horizontal validity: tap s = 0 is invalid for output pixels with x == 0, s = 2 for x == W-1; the lanes that hold such pixels read
+//    a zero row instead (per-lane address select).
+// X image swizzle: 32-byte group index ^= f(row), f(row) = bit1(row) | bit3(row) << 1 -- conflict-free for ds_read_b64_tr_b16 at every
+// row shift (brute-forced over all alignments).
+struct WgradStripArgs {
+  const bf16_t* x; unsigned x_bytes;
+  const bf16_t* dy; unsigned y_bytes;
+  int H, W, C, Cout, M, Kg;
+  int dh, dw;                 // 64 % (H*W) = dh * W + dw
+  int d4, d32, d36;           // 4 % W, 32 % W, 36 % W
+  float rhw, rw;
+  long long slab;             // > 0: split z stores to out + z * slab; 0: float atomics
+  int steps_per_split;
+};
+
+__device__ __forceinline__ int wgx_f(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+template <int BCO>
+__global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, float* __restrict__ out) {
+  constexpr int COT = BCO / 32;               // 16-row co tiles per wave (8 waves: 2 along co x 4 along ci)
+  constexpr int XROWS = 72;                   // 66 needed, 9 LDS-DMA instructions of 8 rows
+  constexpr int XIMG = XROWS * 128, YIMG = WG_BP * 256, STAGE = XIMG + YIMG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;    // wave tile: co [wr*BCO/2, +BCO/2) x ci [wc*16, +16) x 3 taps
+  const int tr = blockIdx.x % 3, cc = blockIdx.x / 3;
+  const int co0 = blockIdx.y * BCO;
+  const int nsteps = (a.M + WG_BP - 1) / WG_BP;
+  const int s_begin = blockIdx.z * a.steps_per_split;
+  const int s_end = min(nsteps, s_begin + a.steps_per_split);
+  if (s_begin >= s_end) return;
+  char* const sZero = smem + 2 * STAGE;
+  if (tid < 8) *reinterpret_cast<uint4*>(sZero + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  constexpr unsigned OOB = 0x80000000u;
+  const int hw = a.H * a.W;
+
+  // ---- X strip loads: instruction ix covers strip rows 8 ix .. +7 (wave w issues ix = w, wave 0 also ix = 8); lane -> row + (lane >> 3),
+  // 16-byte slot lane & 7 holding source chunk slot ^ (f(row) << 1); strip row e = pixel st*64 + (tr-1)*W - 1 + e
+  const int xl_row = lane >> 3;
+  int xe[2], xoff[2], xy[2], xx[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    xe[u] = (u == 0 ? wave : 8) * 8 + xl_row;
+    const int px = s_begin * WG_BP + (tr - 1) * a.W - 1 + xe[u];
+    const int chunk = (lane & 7) ^ (wgx_f(xe[u]) << 1);
+    xoff[u] = (px * a.C + cc * 64 + chunk * 8) * 2;          // negative / beyond the tensor -> out of the buffer range -> zeros
+    int n_, rem;
+    fast_divmod(px + hw, hw, a.rhw, n_, rem);               // px >= -(W + 1) > -H*W
+    fast_divmod(rem, a.W, a.rw, xy[u], xx[u]);
+  }
+  const int bad_y = tr == 0 ? a.H - 1 : (tr == 2 ? 0 : -1);   // strip rows of this image row belong to the neighbouring image / padding
+  const int xstep = WG_BP * a.C * 2;
+  // ---- dY loads (as in the generic kernel): instruction j covers image rows (wave*2 + j)*4 .. +3, 256-byte rows
+  const int lr = lane >> 4, slot = lane & 15;
+  unsigned yoff[2];
+  bool y_cv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ch = slot ^ ((lr << 2) | ((wave * 2 + j) & 3));
+    const int m = s_begin * WG_BP + (wave * 2 + j) * 4 + lr;
+    y_cv[j] = (BCO == 128 || ch < 8);
+    yoff[j] = ((unsigned)m * (unsigned)a.Cout + (unsigned)(co0 + ch * 8)) * 2u;   // m >= M is beyond the buffer -> zeros
+  }
+  const unsigned ystep = (unsigned)(WG_BP * a.Cout * 2);
+
+  // ---- transposed-read geometry: lane (g = lane >> 4, i = lane & 15) reads pixels pk = 8g + (i >> 2) + {0, 4, 32, 36}; X address of
+  // (pk, tap s) = strip row pk + s, 32-byte group wc, 8-byte piece i & 3
+  const int gq = lane >> 4, i16 = lane & 15;
+  const int pbase = 8 * gq + (i16 >> 2);
+  int xaddr[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int row = pbase + (k & 1) * 4 + (k >> 1) * 32 + s;
+      xaddr[k][s] = row * 128 + ((wc ^ wgx_f(row)) << 5) + (i16 & 3) * 8;
+    }
+  const int zaddr = 2 * STAGE;                         // relative to smem
+  // x coordinate of output pixel s_begin*64 + pbase
+  int x0;
+  {
+    int n_, rem, y_;
+    fast_divmod(s_begin * WG_BP + pbase, hw, a.rhw, n_, rem);
+    fast_divmod(rem, a.W, a.rw, y_, x0);
+  }
+
+  f32x4_t acc[COT][3];
+#pragma unroll
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc[c][s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto issue_stage = [&](int buf) {
+    char* sX = smem + buf * STAGE;
+    char* sY = sX + XIMG + wave * 2048;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 0 || wave == 0) {
+        buffer_load_lds16(a.x, a.x_bytes, sX + (u == 0 ? wave : 8) * 1024, xy[u] == bad_y ? OOB : (unsigned)xoff[u]);
+        xoff[u] += xstep;
+        const int w2 = xx[u] + a.dw;
+        const int cw = w2 >= a.W;
+        xx[u] = w2 - (cw ? a.W : 0);
+        const int h2 = xy[u] + a.dh + cw;
+        xy[u] = h2 - (h2 >= a.H ? a.H : 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      buffer_load_lds16(a.dy, a.y_bytes, sY + j * 1024, y_cv[j] ? yoff[j] : OOB);
+      yoff[j] += ystep;
+    }
+  };
+  auto compute_stage = [&](int buf) {
+    const int xb = buf * STAGE;
+    const char* sY = smem + xb + XIMG;
+    // horizontal validity of the 4 pixels of this lane
+    int xk[4];
+    xk[0] = x0;
+    xk[1] = x0 + a.d4;  xk[1] -= xk[1] >= a.W ? a.W : 0;
+    xk[2] = x0 + a.d32; xk[2] -= xk[2] >= a.W ? a.W : 0;
+    xk[3] = x0 + a.d36; xk[3] -= xk[3] >= a.W ? a.W : 0;
+    typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t yf[COT], xf[3];
+#pragma unroll
+      for (int c = 0; c < COT; ++c) yf[c] = tr_frag(sY, ks * 32, wr * (BCO / 2) + c * 16, lane);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        int a0 = xb + xaddr[2 * ks][s], a1 = xb + xaddr[2 * ks + 1][s];
+        if (s == 0) { a0 = xk[2 * ks] == 0 ? zaddr : a0; a1 = xk[2 * ks + 1] == 0 ? zaddr : a1; }
+        if (s == 2) { a0 = xk[2 * ks] == a.W - 1 ? zaddr : a0; a1 = xk[2 * ks + 1] == a.W - 1 ? zaddr : a1; }
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(smem + a0));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(smem + a1));
+        s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        xf[s] = __builtin_bit_cast(bf16x8_t, r);
+      }
+#pragma unroll
+      for (int c = 0; c < COT; ++c)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc[c][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[c], xf[s], acc[c][s], 0, 0, 0);
+    }
+    // advance the lane's pixel cursor by 64
+    x0 += a.dw;
+    x0 -= x0 >= a.W ? a.W : 0;
+  };
+
+  issue_stage(0);
+  for (int st = s_begin; st < s_end; ++st) {
+    const int buf = (st - s_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (st + 1 < s_end) issue_stage(buf ^ 1);
+    compute_stage(buf);
+  }
+
+  // D[row = co][col = ci]: lane holds rows 4*(lane>>4)+j, column lane&15
+  float* dst = out + (a.slab ? (size_t)blockIdx.z * (size_t)a.slab : 0);
+#pragma unroll
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int kc = (tr * 3 + s) * a.C + cc * 64 + wc * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int co = co0 + wr * (BCO / 2) + c * 16 + (lane >> 4) * 4 + j;
+        if (a.slab) dst[(size_t)co * a.Kg + kc] = acc[c][s][j];
+        else        atomicAdd(dst + (size_t)co * a.Kg + kc, acc[c][s][j]);
+      }
+    }
+}
+
 // dW[i] (+)= sum over the split slabs: 256 threads = 64 float4 columns x 4 slab groups (coalesced 1 KiB rows, 4-deep unrolled loads),
 // the groups meet in LDS.  Plain stores + this pass replace the float atomics of the one-pass kernel, which had become 44 % of the
 // weight-gradient time (~0.47 G lane-atomics/us device-wide, while the same bytes as plain stores are nearly free).
@@ -781,6 +965,7 @@ TileCfg pick_tile(int M, int Kout) {
 // strip kernel plan: 0 = not eligible, else the pixel tile BM (and the channel tile through *bnp)
 // tuning overrides (yolo_set_tuning): strip_bm = -1 auto, 0 = never use the strip kernel, 64 / 128 / 256 = force; strip_bn = 0 auto
 int g_strip_bm = -1, g_strip_bn = 0;
+int g_wgrad_strip = 1;   // "wgrad_strip" = 0 keeps the weight gradient of 3x3 stride-1 layers on the generic kernel
 int pick_strip(const Gather& g, int Kout, bool f32, int* bnp = nullptr) {
   if (f32 || g.den != 1 || g.C0 != 0 || g.S != 3 || g.RS != 9 || g.smul != 1 || g.pad_h != 1 || g.pad_w != 1) return 0;
   if (g.Hs != g.Ho || g.Ws != g.Wo || g.C1 % 64 != 0 || Kout % 64 != 0) return 0;
@@ -901,6 +1086,7 @@ int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int l
 extern "C" int yolo_set_tuning(const char* name, int value) {
   YOLO_CHECK_ARG(name != nullptr, "null name");
   if (!strcmp(name, "strip_bm")) { YOLO_CHECK_ARG(value == -1 || value == 0 || value == 64 || value == 128 || value == 256, "strip_bm"); g_strip_bm = value; }
+  else if (!strcmp(name, "wgrad_strip")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_strip"); g_wgrad_strip = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
   return YOLO_OK;
@@ -947,7 +1133,7 @@ extern "C" int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, con
 }
 
 namespace {
-struct WgradPlan { Gather g; int bco, tiles_k, tiles_c, split_k, sps; };
+struct WgradPlan { Gather g; int bco, tiles_k, tiles_c, split_k, sps; bool strip; };
 
 // split-K plan: at most `target` workgroups (2 per CU: 64 KiB of LDS each) so that the whole grid is resident in one round -- one
 // workgroup more than the slots costs a second, almost empty round -- and at least 8 pixel-steps per workgroup
@@ -958,7 +1144,10 @@ int plan_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, i
   pl->g = fwd_gather(p, src0, src1);
   YOLO_CHECK_ARG(pl->g.M < (1 << 24), "wgrad row decode needs N*Ho*Wo < 2^24");
   pl->bco = (p->Cout % 128 == 0) ? 128 : 64;
-  pl->tiles_k = (pl->g.Kg + WG_BKC - 1) / WG_BKC;
+  pl->strip = g_wgrad_strip && p->R == 3 && p->S == 3 && p->stride == 1 && p->pad_t == 1 && p->pad_l == 1 && p->Ho == p->H &&
+              p->Wo == p->W && p->C0 == 0 && p->Cin % 64 == 0 && (size_t)p->N * p->H * p->W * p->Cin * 2 < (1ull << 31) &&
+              (size_t)pl->g.M * p->Cout * 2 < (1ull << 31);
+  pl->tiles_k = pl->strip ? 3 * (p->Cin / 64) : (pl->g.Kg + WG_BKC - 1) / WG_BKC;
   pl->tiles_c = (p->Cout + pl->bco - 1) / pl->bco;
   const int nsteps = (pl->g.M + WG_BP - 1) / WG_BP;
   if (split_k <= 0) {
@@ -977,6 +1166,21 @@ int plan_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, i
 // slab = 0: float atomics into out; slab > 0: split z stores its partial tile to out + z * slab
 void launch_wgrad(const yolo_conv_problem* p, const WgradPlan& pl, const void* dy, float* out, long long slab, hipStream_t stream) {
   const Gather& g = pl.g;
+  if (pl.strip) {
+    WgradStripArgs a;
+    a.x = g.src1; a.x_bytes = (unsigned)((size_t)p->N * p->H * p->W * p->Cin * 2);
+    a.dy = (const bf16_t*)dy; a.y_bytes = (unsigned)((size_t)g.M * p->Cout * 2);
+    a.H = p->H; a.W = p->W; a.C = p->Cin; a.Cout = p->Cout; a.M = g.M; a.Kg = g.Kg;
+    const int hw = p->H * p->W;
+    a.dh = (WG_BP % hw) / p->W; a.dw = (WG_BP % hw) % p->W;
+    a.d4 = 4 % p->W; a.d32 = 32 % p->W; a.d36 = 36 % p->W;
+    a.rhw = g.rhw; a.rw = g.rw; a.slab = slab; a.steps_per_split = pl.sps;
+    const dim3 grid(pl.tiles_k, pl.tiles_c, pl.split_k);
+    const size_t lds = 2 * (72 * 128 + WG_BP * 256) + 128;
+    if (pl.bco == 128) hipLaunchKernelGGL(wgrad3x3_strip_kernel<128>, grid, dim3(512), lds, stream, a, out);
+    else               hipLaunchKernelGGL(wgrad3x3_strip_kernel<64>, grid, dim3(512), lds, stream, a, out);
+    return;
+  }
   const size_t lds = 2 * 2 * WG_BP * 256;
   // 64 pixels = dn images + dh rows + dw columns of the output grid
   WgradStep ws;
