@@ -129,6 +129,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay two hipGraphs instead of eager two-stream launches (measured slower: the '
                     'forked weight-gradient branch is serialised under replay)')
     ap.add_argument('--no-overlap', action='store_true', help='weight-gradient GEMMs on the main stream')
+    ap.add_argument('--no-fused-bn', action='store_true', help='three-kernel BatchNorm backward instead of the single-launch one')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -147,6 +148,7 @@ def main():
     model, loss, opt, grids = build_model(args.backbone, H, W, args.batch, args.classes, device)
     model.use_hip_graph = bool(args.graph)
     model.overlap_wgrad = not args.no_overlap
+    model.g.fused_bn_bwd = not args.no_fused_bn
     if world > 1:
         from yolov3_tensorflow_amd import parallel
         parallel.setup_data_parallel(model)

@@ -53,7 +53,8 @@ typedef struct {
  * stat_rows = yolo_conv2d_stat_rows(p) (reduced later by yolo_bn_finalize). */
 int yolo_conv2d_stat_rows(const yolo_conv_problem* p);
 /* Test / benchmark hook: override a kernel-selection heuristic.  "strip_bm": -1 auto (default), 0 never use the LDS-resident strip
- * kernel for 3x3 stride-1 convolutions, 64 / 128 / 256 force its pixel tile; "strip_bn": 0 auto, 64 / 128.  Changes
+ * kernel for 3x3 stride-1 convolutions, 64 / 128 / 256 force its pixel tile; "strip_bn": 0 auto, 64 / 128; "wgrad_strip": 0 / 1;
+ * "bn_fused_min_chunks": smallest per-thread chunk count (1..12, default 3) served by yolo_bn_act_bwd_fused.  Changes
  * yolo_conv2d_stat_rows() accordingly: set it before sizing statistics buffers. */
 int yolo_set_tuning(const char* name, int value);
 int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd, const float* bias,
@@ -110,6 +111,19 @@ int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu, const voi
                           const float* rstd, const float* k1, const float* k2, void* dy, int acc_dy, const void* y2, const float* a2,
                           const float* mean2, const float* rstd2, const float* k1b, const float* k2b, void* dy2, void* dres,
                           int acc_dres, int64_t M, int C, void* stream);
+/* The three calls above in ONE launch for a BN-carrying main branch (training hot path): the grid is resident (one 1024-thread
+ * workgroup per CU), every workgroup keeps the masked gradient of its slice in registers, the last one to arrive finalizes
+ * (dgamma / dbeta written, NULL = skip) and the apply runs from the held values, so dout / out are read once.  workspace: at least
+ * yolo_bn_bwd_fused_workspace_floats(C) floats; sync_words: yolo_bn_bwd_fused_sync_words() ints zeroed once by the caller (grid-barrier
+ * counters that only ever grow, plus a count of spin time-outs: read it with yolo_bn_fused_timeouts).  Returns 1 without launching when M*C is too large for the register-resident scheme (the caller
+ * falls back to reduce / finalize / apply), 0 on success. */
+int64_t yolo_bn_bwd_fused_workspace_floats(int C);
+int yolo_bn_bwd_fused_sync_words(void);
+int yolo_bn_act_bwd_fused(const void* dout, const void* out, int relu, int64_t M, int C, const void* y, const float* a1,
+                          const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dy, int acc_dy, const void* y2,
+                          const float* a2, const float* mean2, const float* rstd2, float* dgamma2, float* dbeta2, void* dy2,
+                          void* dres, int acc_dres, float* workspace, int* sync_words, void* stream);
+int yolo_bn_fused_timeouts(const int* sync_words, int* host_out);
 /* the same two passes through the stem's max-pool (rows = pre-pool pixels N*H*W) */
 /* (with relu and non-NULL gamma/beta the sums are taken over the pooled map: xhat = (out - beta) / gamma, y/argmax are not read) */
 int yolo_bn_pool_bwd_reduce(const void* dout, const void* out, const uint8_t* argmax, int relu, const void* y, const float* mean,

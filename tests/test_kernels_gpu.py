@@ -337,6 +337,78 @@ def test_bn_act_fwd_bwd(dev, mode):
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize('M,Cc,mode', [(32 * 13 * 13, 512, 'plain'), (32 * 26 * 26, 256, 'res'), (32 * 52 * 52, 128, 'bn2'),
+                                       (3001, 64, 'res_acc'), (32 * 104 * 104, 64, 'plain'), (32 * 104 * 104 * 2, 64, 'too_big')])
+def test_bn_bwd_fused_matches_three_kernel_path(dev, M, Cc, mode):
+    """the single-launch BatchNorm backward (resident grid, device-wide hand-off) against reduce / finalize / apply on the same inputs:
+    plain BN+ReLU, identity residual (with and without fan-in accumulation), shortcut-BN branch, 2 / 6 / 11 chunks per thread, a ragged
+    size, and the size it has to refuse; two launches in a row reuse the (monotonic) barrier word"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(M % 1000 + Cc)
+    y = bf(torch.randn(M, Cc, generator=g) * 1.5 + 0.3).to(dev)
+    y2 = bf(torch.randn(M, Cc, generator=g)).to(dev)
+    dout = bf(torch.randn(M, Cc, generator=g)).to(dev)
+    out = bf(torch.randn(M, Cc, generator=g)).to(dev)           # stands for relu(...) > 0 mask: sign pattern only
+    prev = bf(torch.randn(M, Cc, generator=g)).to(dev)
+    mean, rstd = torch.randn(Cc, generator=g).to(dev) * 0.2, (torch.rand(Cc, generator=g) + 0.5).to(dev)
+    mean2, rstd2 = torch.randn(Cc, generator=g).to(dev) * 0.2, (torch.rand(Cc, generator=g) + 0.5).to(dev)
+    a1, a2 = (torch.randn(Cc, generator=g)).to(dev), (torch.randn(Cc, generator=g)).to(dev)
+    has2, res, acc = mode == 'bn2', mode in ('res', 'res_acc'), mode == 'res_acc'
+
+    # three-kernel path
+    P = ops.reduce_rows(M, Cc)
+    partial = torch.zeros(P, 3, Cc, device=dev)
+    dg, db, k1, k2 = [torch.zeros(Cc, device=dev) for _ in range(4)]
+    dg2, db2, k1b, k2b = [torch.zeros(Cc, device=dev) for _ in range(4)]
+    ops.bn_act_bwd_reduce(dout, out, True, y, mean, rstd, M, Cc, partial, y2=y2 if has2 else None, mean2=mean2 if has2 else None,
+                          rstd2=rstd2 if has2 else None)
+    ops.bn_bwd_finalize(partial.view(-1), P, Cc, 1, M, dg, db, k1, k2)
+    kw = {}
+    if has2:
+        ops.bn_bwd_finalize(partial.view(-1), P, Cc, 2, M, dg2, db2, k1b, k2b)
+        dy2_ref = torch.empty_like(y)
+        kw.update(y2=y2, a2=a2, mean2=mean2, rstd2=rstd2, k1b=k1b, k2b=k2b, dy2=dy2_ref)
+    dy_ref = prev.clone()
+    dres_ref = prev.clone()
+    if res:
+        kw.update(dres=dres_ref, acc_dres=acc)
+    ops.bn_act_bwd_apply(dout, out, True, M, Cc, y=y, a1=a1, mean=mean, rstd=rstd, k1=k1, k2=k2, dy=dy_ref, acc_dy=acc, **kw)
+
+    ops.set_tuning('bn_fused_min_chunks', 1)          # also exercise the small sizes the heuristic leaves to the three-kernel path
+    ws = torch.zeros(ops.bn_bwd_fused_workspace_floats(Cc), device=dev)
+    sync = torch.zeros(ops.bn_bwd_fused_sync_words(), dtype=torch.int32, device=dev)
+    for rep in range(2):
+        fdg, fdb, fdg2, fdb2 = [torch.zeros(Cc, device=dev) for _ in range(4)]
+        dy = prev.clone()
+        dres = prev.clone()
+        dy2 = torch.empty_like(y)
+        kw = {}
+        if has2:
+            kw.update(y2=y2, a2=a2, mean2=mean2, rstd2=rstd2, dgamma2=fdg2, dbeta2=fdb2, dy2=dy2)
+        if res:
+            kw.update(dres=dres, acc_dres=acc)
+        ok = ops.bn_act_bwd_fused(dout, out, True, M, Cc, y, a1, mean, rstd, fdg, fdb, dy, ws, sync, acc_dy=acc, **kw)
+        if mode == 'too_big':
+            assert not ok
+            ops.set_tuning('bn_fused_min_chunks', 3)
+            return
+        assert ok
+        torch.cuda.synchronize()
+        assert ops.bn_fused_timeouts(sync) == 0
+        assert int(sync[0]) > 0 and int(sync[0]) % (2 * (rep + 1)) == 0      # shard 0: two grid barriers per launch
+        scale = max(dg.abs().max().item(), 1.0)
+        torch.testing.assert_close(fdg, dg, rtol=2e-4, atol=2e-5 * scale)
+        torch.testing.assert_close(fdb, db, rtol=2e-4, atol=2e-5 * max(db.abs().max().item(), 1.0))
+        # same formula, constants folded differently (A g + B y + D): within a bf16 ulp of the reference result
+        torch.testing.assert_close(dy.float(), dy_ref.float(), rtol=2 ** -7, atol=2e-2)
+        if has2:
+            torch.testing.assert_close(fdg2, dg2, rtol=2e-4, atol=2e-5 * max(dg2.abs().max().item(), 1.0))
+            torch.testing.assert_close(dy2.float(), dy2_ref.float(), rtol=2 ** -7, atol=2e-2)
+        if res:
+            assert torch.equal(dres, dres_ref) or torch.allclose(dres.float(), dres_ref.float(), rtol=2 ** -8, atol=0)
+    ops.set_tuning('bn_fused_min_chunks', 3)
+
+
 def test_bn_pool_relu_fwd_bwd(dev):
     """stem: conv -> BN -> maxpool(3,2,'same') -> ReLU (resnet18.py:59-61) and its backward"""
     from yolov3_tensorflow_amd import ops

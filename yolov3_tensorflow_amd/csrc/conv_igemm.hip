@@ -1083,10 +1083,13 @@ int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int l
 
 }  // namespace
 
+extern int g_fused_min_chunks;   // eltwise.hip
+
 extern "C" int yolo_set_tuning(const char* name, int value) {
   YOLO_CHECK_ARG(name != nullptr, "null name");
   if (!strcmp(name, "strip_bm")) { YOLO_CHECK_ARG(value == -1 || value == 0 || value == 64 || value == 128 || value == 256, "strip_bm"); g_strip_bm = value; }
   else if (!strcmp(name, "wgrad_strip")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_strip"); g_wgrad_strip = value; }
+  else if (!strcmp(name, "bn_fused_min_chunks")) { YOLO_CHECK_ARG(value >= 1 && value <= 12, "bn_fused_min_chunks"); g_fused_min_chunks = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
   return YOLO_OK;

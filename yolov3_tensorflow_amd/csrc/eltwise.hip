@@ -415,6 +415,212 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// BatchNorm(+ReLU, + residual / second BN branch) backward in ONE launch: reduce, finalize and apply of the three-kernel path above.
+// ------------------------------------------------------------------------------------------------------------------
+// The whole grid is resident (<= one 1024-thread workgroup per CU, <= 128 VGPRs), so a device-wide hand-off is safe: every workgroup
+// reduces its slice and keeps the masked gradient g of its elements in registers (bf16, 4 VGPRs per 8 elements; the largest layer of
+// the 416^2 / batch-32 workload needs 11 chunks per thread = the register file holding 44 MB), publishes a partial row and arrives at
+// a counter; the workgroup that arrives last sums the rows (double), writes dgamma / dbeta / k1 / k2 and raises a flag; everybody then
+// applies dy = a (g - k1 - xhat k2) from the held g, re-reading only y.  dout and out are read once instead of twice, two launches and
+// their drain / fill gaps disappear.  The hand-off follows the CDNA guide's store-side recipe: every handed-off word is written with a
+// device-coherent (sc1) store and drained (s_waitcnt vmcnt(0) + workgroup barrier) before the counter / flag, and read with sc1 loads
+// after a workgroup barrier behind the polling lane; it cleans up after itself (the last workgroup to leave re-zeroes the words), so it is replayable.  A bounded spin turns a protocol failure into
+// a counted timeout (yolo_bn_fused_timeouts) instead of a hang.
+// device-coherent accesses for the handed-off words (partial rows, k1 / k2): sc1 stores / loads that bypass the per-XCD L2, so the hand-off
+// needs no L2 write-back / invalidate (buffer_wbl2 / buffer_inv from 256 workgroups had cost ~40 us per launch)
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Grid barrier for a fully resident grid, executed by wave 0 of each workgroup.  256 adds to ONE device-scope word serialise at the memory
+// side (~25 us per barrier measured), so the arrival counter is sharded over 16 words on separate 128-byte lines (workgroup b adds to
+// shard b & 15: 16 adds per word) and lanes 0..15 poll one shard each.  The words grow monotonically: the generation of a barrier is
+// derived from the value the workgroup's own add returned, so nothing is ever reset (replayable).  Polls are relaxed device-scope loads
+// with s_sleep between them; a bounded spin counts a time-out in sync[FB_TIMEOUT_WORD] instead of hanging.
+constexpr int FB_SPIN_LIMIT = 2000000;   // x ~0.3 us
+constexpr int FB_SHARDS = 16, FB_SHARD_STRIDE = 32, FB_TIMEOUT_WORD = FB_SHARDS * FB_SHARD_STRIDE, FB_SYNC_WORDS = FB_TIMEOUT_WORD + 32;
+__device__ __forceinline__ void grid_arrive_wait(int* sync) {
+  const unsigned G = gridDim.x, lane = threadIdx.x & 63;
+  const unsigned s = blockIdx.x & (FB_SHARDS - 1), ns = (G - s + FB_SHARDS - 1) / FB_SHARDS;
+  unsigned gen = 0;
+  if (lane == 0) gen = (unsigned)__hip_atomic_fetch_add(sync + s * FB_SHARD_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / ns + 1u;
+  gen = __shfl(gen, 0, 64);
+  const unsigned nl = lane < FB_SHARDS && lane < G ? (G - lane + FB_SHARDS - 1) / FB_SHARDS : 0u;
+  const unsigned target = gen * nl;
+  int spins = 0;
+  for (;;) {
+    bool ok = true;
+    if (nl) ok = (int)((unsigned)__hip_atomic_load(sync + lane * FB_SHARD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(4);
+    if (++spins > FB_SPIN_LIMIT) { if (lane == 0) atomicAdd(sync + FB_TIMEOUT_WORD, 1); break; }
+  }
+}
+
+struct FusedBwdArgs {
+  const bf16_t* dout; const bf16_t* out; int relu;
+  const bf16_t* y; const float* a1; const float* mean; const float* rstd; float* dgamma; float* dbeta; bf16_t* dy; int acc_dy;
+  const bf16_t* y2; const float* a2; const float* mean2; const float* rstd2; float* dgamma2; float* dbeta2; bf16_t* dy2;
+  bf16_t* dres; int acc_dres;
+  size_t total;       // M * C / 8 chunks
+  int C; float count;
+  float* partial;     // [grid][3][C]
+  float* kbuf;        // [3][C] column totals: sum g, sum g xhat, sum g xhat2
+  int* sync;          // FB_SYNC_WORDS ints: sharded arrival counters + the time-out count
+};
+constexpr int FB_THREADS = 1024;
+
+template <int MAXCH, bool HAS2>
+__global__ __launch_bounds__(FB_THREADS) void bn_bwd_fused_kernel(FusedBwdArgs a) {
+  __shared__ float red[FB_THREADS * 8];              // [RL][C] floats (RL * C == 8192), one quantity at a time; later the column totals
+  const int C = a.C, CV = C >> 3;
+  const size_t T = (size_t)gridDim.x * FB_THREADS;
+  const size_t t0 = (size_t)blockIdx.x * FB_THREADS + threadIdx.x;
+  const int cv = (int)(t0 % CV), c0 = cv * 8;        // T % CV == 0: the channel chunk of a thread is fixed
+  float mu[8], rs[8], mu2[8], rs2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = a.mean[c0 + j]; rs[j] = a.rstd[c0 + j];
+    mu2[j] = HAS2 ? a.mean2[c0 + j] : 0.f; rs2[j] = HAS2 ? a.rstd2[c0 + j] : 0.f;
+  }
+  // ---- phase 1: masked gradient into registers, per-thread sums
+  uint4 gk[MAXCH];
+  float acc[3][8] = {};
+#pragma unroll
+  for (int k = 0; k < MAXCH; ++k) {
+    const size_t i = t0 + (size_t)k * T;
+    gk[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < a.total) {
+      uint4 d = ld16(a.dout + i * 8);
+      if (a.relu) {   // g = dout where out > 0 (bf16 sign / zero test on the packed halves)
+        const uint4 o = ld16(a.out + i * 8);
+        const unsigned ow[4] = {o.x, o.y, o.z, o.w};
+        unsigned dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned lo = ow[q] & 0xffffu, hi = ow[q] >> 16;
+          const bool plo = lo != 0u && lo < 0x8000u, phi = hi != 0u && hi < 0x8000u;     // > 0 (NaN counts as positive, as o > 0.f is false
+          dw[q] = (plo ? (dw[q] & 0xffffu) : 0u) | (phi ? (dw[q] & 0xffff0000u) : 0u);   //  for NaN this differs, but out is finite)
+        }
+        d = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+      }
+      gk[k] = d;
+      float g[8], v[8];
+      unpack_bf8(d, g);
+      unpack_bf8(ld16(a.y + i * 8), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc[0][j] += g[j]; acc[1][j] += g[j] * ((v[j] - mu[j]) * rs[j]); }
+      if (HAS2) {
+        unpack_bf8(ld16(a.y2 + i * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[2][j] += g[j] * ((v[j] - mu2[j]) * rs2[j]);
+      }
+    }
+  }
+  // block partial row: threads with the same cv (row lanes rl = tid / CV) meet in LDS
+  {
+    float* r = red;
+    const int RL = FB_THREADS / CV, rl = threadIdx.x / CV;
+    constexpr int K = HAS2 ? 3 : 2;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[rl * C + c0 + j] = acc[k][j];
+      __syncthreads();
+      for (int c = threadIdx.x; c < C; c += FB_THREADS) {
+        float s = 0.f;
+        for (int q = 0; q < RL; ++q) s += r[q * C + c];
+        st_agent(a.partial + ((size_t)blockIdx.x * 3 + k) * C + c, s);
+      }
+    }
+  }
+  // ---- grid barrier 1: every partial row is published
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's device-coherent partial-row stores are acknowledged ...
+  __syncthreads();                                   // ... before the workgroup's arrival is counted
+  if (threadIdx.x < 64) grid_arrive_wait(a.sync);
+  __syncthreads();
+  // ---- column totals, spread over the grid: workgroup b owns columns b, b + G, ... of the [3][C] quantities; 4 columns at a time,
+  // 256 threads (one per partial row) each, double sums through wave shuffles + LDS
+  {
+    const int G = (int)gridDim.x, ncol = (HAS2 ? 3 : 2) * C;
+    double* dred = reinterpret_cast<double*>(red);
+    const int slot = threadIdx.x >> 8, row = threadIdx.x & 255;
+    for (int k0 = 0; (int)blockIdx.x + G * k0 < ncol; k0 += 4) {
+      const int col = (int)blockIdx.x + G * (k0 + slot);
+      double v = 0.0;
+      if (col < ncol) {
+        const int q = col / C, c = col - q * C;
+        for (int p = row; p < G; p += 256) v += (double)ld_agent(a.partial + ((size_t)p * 3 + q) * C + c);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = v;      // 16 wave sums: 4 per column slot
+      __syncthreads();
+      if (row == 0 && col < ncol) {
+        const float tot = (float)((dred[slot * 4] + dred[slot * 4 + 1]) + (dred[slot * 4 + 2] + dred[slot * 4 + 3]));
+        const int q = col / C, c = col - q * C;
+        st_agent(a.kbuf + col, tot);
+        if (q == 0) { if (a.dbeta) a.dbeta[c] = tot; if (HAS2 && a.dbeta2) a.dbeta2[c] = tot; }
+        if (q == 1 && a.dgamma) a.dgamma[c] = tot;
+        if (HAS2 && q == 2 && a.dgamma2) a.dgamma2[c] = tot;
+      }
+    }
+  }
+  // ---- grid barrier 2: every column total is published
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < 64) grid_arrive_wait(a.sync);
+  __syncthreads();
+  // ---- phase 2: dy = A g + B y + D per channel
+  float A[8], B[8], D[8], A2[8], B2[8], D2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float k1 = ld_agent(a.kbuf + c0 + j) / a.count, k2 = ld_agent(a.kbuf + C + c0 + j) / a.count;
+    const float aa = a.a1[c0 + j];
+    A[j] = aa; B[j] = -aa * rs[j] * k2; D[j] = aa * (mu[j] * rs[j] * k2 - k1);
+    if (HAS2) {
+      const float k1b = k1, k2b = ld_agent(a.kbuf + 2 * C + c0 + j) / a.count;
+      const float ab = a.a2[c0 + j];
+      A2[j] = ab; B2[j] = -ab * rs2[j] * k2b; D2[j] = ab * (mu2[j] * rs2[j] * k2b - k1b);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXCH; ++k) {
+    const size_t i = t0 + (size_t)k * T;
+    if (i < a.total) {
+      float g[8], v[8], o[8];
+      unpack_bf8(gk[k], g);
+      unpack_bf8(ld16(a.y + i * 8), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = A[j] * g[j] + (B[j] * v[j] + D[j]);
+      if (a.acc_dy) {
+        unpack_bf8(ld16(a.dy + i * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += v[j];
+      }
+      st16(a.dy + i * 8, pack_bf8(o));
+      if (HAS2) {
+        unpack_bf8(ld16(a.y2 + i * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = A2[j] * g[j] + (B2[j] * v[j] + D2[j]);
+        st16(a.dy2 + i * 8, pack_bf8(o));
+      }
+      if (a.dres) {
+        if (a.acc_dres) {
+          unpack_bf8(ld16(a.dres + i * 8), v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[j] += v[j];
+          st16(a.dres + i * 8, pack_bf8(g));
+        } else {
+          st16(a.dres + i * 8, gk[k]);
+        }
+      }
+    }
+  }
+}
+
 // ---- gradient split of concat(upsample2x(a[N,H/2,W/2,C0]), b[N,H,W,C1]) given dcat[N,H,W,C0+C1] ----
 __global__ __launch_bounds__(EW_THREADS) void upcat_split_kernel(const bf16_t* __restrict__ dcat, bf16_t* __restrict__ da, int acc_a,
                                                                  bf16_t* __restrict__ db, int acc_b, int N, int H, int W, int C0, int C1) {
@@ -509,6 +715,19 @@ inline int reduce_grid(int M, int C) {
 
 }  // namespace
 
+// ---- host side of the fused backward
+int g_fused_min_chunks = 3;
+inline int fused_grid() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 64;
+    n = cus > 256 ? 256 : cus;
+  }
+  return n;
+}
+
 extern "C" int yolo_reduce_rows(int M, int C) { return chan_ok(C) && M > 0 ? reduce_grid(M, C) : YOLO_ERR_INVALID_ARG; }
 
 extern "C" int yolo_bn_stats(const void* x, int M, int C, float* partial, void* stream) {
@@ -589,6 +808,48 @@ extern "C" int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu
   hipLaunchKernelGGL(bn_bwd_apply_kernel<PlainGrad>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, gp, (const bf16_t*)y, a1,
                      mean, rstd, k1, k2, (bf16_t*)dy, acc_dy, (const bf16_t*)y2, a2, mean2, rstd2, k1b, k2b, (bf16_t*)dy2, (bf16_t*)dres,
                      acc_dres, (size_t)M, C);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+// Single-launch BatchNorm backward (see bn_bwd_fused_kernel).  workspace: floats, >= yolo_bn_bwd_fused_workspace_floats(C); sync:
+// yolo_bn_bwd_fused_sync_words() ints, zeroed once by the caller.  Returns 1 (and launches nothing) when the tensor does not fit the resident grid's registers: the caller
+// then uses the reduce / finalize / apply path.
+extern "C" int64_t yolo_bn_bwd_fused_workspace_floats(int C) { return C > 0 ? (int64_t)(256 * 3 + 4) * C : 0; }
+extern "C" int yolo_bn_bwd_fused_sync_words(void) { return FB_SYNC_WORDS; }
+
+extern "C" int yolo_bn_fused_timeouts(const int* sync_words, int* host_out) {
+  YOLO_CHECK_ARG(sync_words && host_out, "null pointer");
+  hipError_t e = hipMemcpy(host_out, sync_words + FB_TIMEOUT_WORD, sizeof(int), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { yolo_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); return (int)e; }
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_act_bwd_fused(const void* dout, const void* out, int relu, int64_t M, int C, const void* y, const float* a1,
+                                     const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dy, int acc_dy,
+                                     const void* y2, const float* a2, const float* mean2, const float* rstd2, float* dgamma2,
+                                     float* dbeta2, void* dy2, void* dres, int acc_dres, float* workspace, int* sync_words, void* stream) {
+  YOLO_CHECK_ARG(dout && y && a1 && mean && rstd && dy && workspace && sync_words && M > 0 && chan_ok(C), "bad argument");
+  YOLO_CHECK_ARG(!relu || out, "relu needs out");
+  YOLO_CHECK_ARG(!y2 || (a2 && mean2 && rstd2 && dy2), "second BN branch incomplete");
+  const int G = fused_grid();
+  const size_t total = (size_t)M * (C / 8), T = (size_t)G * FB_THREADS;
+  const size_t need = (total + T - 1) / T;
+  // small tensors stay on the three-kernel path: the two grid barriers cost ~20 us, more than the second read of a tensor that is
+  // L2 / Infinity-Cache resident anyway (measured: 13 x 13 and 26 x 26 maps 25 us fused vs 22 us in three launches)
+  if (need > 11 || (y2 && need > 6) || need < (size_t)g_fused_min_chunks) return 1;
+  FusedBwdArgs a;
+  a.dout = (const bf16_t*)dout; a.out = (const bf16_t*)out; a.relu = relu;
+  a.y = (const bf16_t*)y; a.a1 = a1; a.mean = mean; a.rstd = rstd; a.dgamma = dgamma; a.dbeta = dbeta; a.dy = (bf16_t*)dy; a.acc_dy = acc_dy;
+  a.y2 = (const bf16_t*)y2; a.a2 = a2; a.mean2 = mean2; a.rstd2 = rstd2; a.dgamma2 = dgamma2; a.dbeta2 = dbeta2; a.dy2 = (bf16_t*)dy2;
+  a.dres = (bf16_t*)dres; a.acc_dres = acc_dres;
+  a.total = total; a.C = C; a.count = (float)M;
+  a.partial = workspace; a.kbuf = workspace + (size_t)256 * 3 * C; a.sync = sync_words;
+  hipStream_t st = (hipStream_t)stream;
+#define YOLO_FB(MAXCH_, HAS2_) hipLaunchKernelGGL((bn_bwd_fused_kernel<MAXCH_, HAS2_>), dim3(G), dim3(FB_THREADS), 0, st, a)
+  if (y2) { if (need <= 2) YOLO_FB(2, true); else YOLO_FB(6, true); }
+  else    { if (need <= 2) YOLO_FB(2, false); else if (need <= 6) YOLO_FB(6, false); else YOLO_FB(11, false); }
+#undef YOLO_FB
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

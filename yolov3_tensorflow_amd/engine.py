@@ -168,6 +168,7 @@ class Graph(object):
         self.dev = device
         self.ps = ParamStore(seed)
         self.tape = []
+        self.fused_bn_bwd = True         # single-launch BatchNorm backward where the tensor fits (ops.bn_act_bwd_fused)
         self.vals = []
         self.bns = []            # every keras BatchNormalization (for checkpoints)
         self.bn_groups = []      # allocation units: a BNState or a MultiBN
@@ -361,6 +362,10 @@ class Graph(object):
         # one slab workspace for the two-phase weight gradients (they run back to back on one stream)
         ws_bytes = max([ops.conv2d_wgrad_workspace_bytes(op.y.p) for op in self.tape if isinstance(op, ConvOp)] + [16])
         self.wgrad_ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        # workspace + hand-off words of the single-launch BatchNorm backward (all on the main stream, one at a time)
+        cmax = max([op.out.shape[3] for op in self.tape if isinstance(op, ApplyOp)] + [8])
+        self.bn_ws = torch.zeros(ops.bn_bwd_fused_workspace_floats(cmax), dtype=torch.float32, device=dev)
+        self.bn_sync = torch.zeros(ops.bn_bwd_fused_sync_words(), dtype=torch.int32, device=dev)
         for op in self.tape:
             op.bind()
         self.fwd = [lambda: ops.pack_input(self.images, self.input_val.buf, N * H * W, C)]
@@ -615,6 +620,17 @@ class ApplyOp(object):
     def backward(self):
         out, m, o = self.out, self.m_src, self.o_src
         mb, ob = self.m_bn, self.o_bn
+        if self.g.fused_bn_bwd and mb is not None and len(mb.parts) == 1 and (ob is None or len(ob.parts) == 1):
+            kw = {}
+            if o is not None:
+                if ob is not None:
+                    kw.update(y2=o.buf, a2=ob.scale, mean2=ob.mean, rstd2=ob.rstd, dgamma2=ob.v_dgamma, dbeta2=ob.v_dbeta, dy2=o.dy)
+                else:
+                    kw.update(dres=o.grad, acc_dres=self.o_acc)
+            if ops.bn_act_bwd_fused(out.grad, out.buf, self.relu, self.M, self.C, m.buf, mb.scale, mb.mean, mb.rstd, mb.v_dgamma,
+                                    mb.v_dbeta, m.dy if self.m_dst == 'dy' else m.grad, self.g.bn_ws, self.g.bn_sync,
+                                    acc_dy=self.m_acc, **kw):
+                return
         if mb is not None or ob is not None:
             # quantity 1 of the reduction belongs to the main BN if there is one, else to the shortcut BN
             y1, b1 = (m, mb) if mb is not None else (o, ob)

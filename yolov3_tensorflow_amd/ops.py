@@ -132,6 +132,32 @@ def bn_act_bwd_apply(dout, out, relu, M, Cc, y=None, a1=None, mean=None, rstd=No
                                             int(acc_dres), M, Cc, _stream()), 'yolo_bn_act_bwd_apply')
 
 
+def bn_bwd_fused_workspace_floats(Cc):
+    return int(_lib.load().yolo_bn_bwd_fused_workspace_floats(Cc))
+
+
+def bn_bwd_fused_sync_words():
+    return int(_lib.load().yolo_bn_bwd_fused_sync_words())
+
+
+def bn_act_bwd_fused(dout, out, relu, M, Cc, y, a1, mean, rstd, dgamma, dbeta, dy, workspace, sync, acc_dy=False, y2=None, a2=None,
+                     mean2=None, rstd2=None, dgamma2=None, dbeta2=None, dy2=None, dres=None, acc_dres=False):
+    """single-launch BN(+ReLU, + residual / second BN) backward; returns False (nothing launched) if the tensor is too large for it"""
+    rc = _lib.load().yolo_bn_act_bwd_fused(_p(dout), _p(out), int(relu), M, Cc, _p(y), _p(a1), _p(mean), _p(rstd), _p(dgamma), _p(dbeta),
+                                           _p(dy), int(acc_dy), _p(y2), _p(a2), _p(mean2), _p(rstd2), _p(dgamma2), _p(dbeta2), _p(dy2),
+                                           _p(dres), int(acc_dres), _p(workspace), _p(sync), _stream())
+    if rc == 1:
+        return False
+    check(rc, 'yolo_bn_act_bwd_fused')
+    return True
+
+
+def bn_fused_timeouts(sync):
+    n = C.c_int(0)
+    check(_lib.load().yolo_bn_fused_timeouts(_p(sync), C.byref(n)), 'yolo_bn_fused_timeouts')
+    return n.value
+
+
 def bn_pool_bwd_reduce(dout, out, argmax, relu, y, mean, rstd, N, H, W, Cc, Ho, Wo, pt, pl, partial, gamma=None, beta=None):
     check(_lib.load().yolo_bn_pool_bwd_reduce(_p(dout), _p(out), _p(argmax), int(relu), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta),
                                               N, H, W, Cc, Ho, Wo, pt, pl, _p(partial), _stream()), 'yolo_bn_pool_bwd_reduce')
