@@ -149,6 +149,10 @@ def main():
     model.use_hip_graph = bool(args.graph)
     model.overlap_wgrad = not args.no_overlap
     model.g.fused_bn_bwd = not args.no_fused_bn
+    from yolov3_tensorflow_amd import ops
+    for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):      # kernel-selection overrides for A/B runs (yolo_set_tuning)
+        k, v = kv.split('=')
+        ops.set_tuning(k, int(v))
     if world > 1:
         from yolov3_tensorflow_amd import parallel
         parallel.setup_data_parallel(model)

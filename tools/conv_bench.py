@@ -15,6 +15,8 @@ LAYERS = {   # name: (H, W, Cin, Cout, k, stride, padding)
     '256': (26, 26, 256, 256, 3, 1, 'same'),
     '512': (13, 13, 512, 512, 3, 1, 'same'),
     '128s2': (104, 104, 64, 128, 3, 2, 'same'),
+    '256s2': (52, 52, 128, 256, 3, 2, 'same'),
+    '512s2': (26, 26, 256, 512, 3, 2, 'same'),
     '1x1': (52, 52, 256, 128, 1, 1, 'same'),
     'h13': (13, 13, 512, 256, 3, 1, 'same'),
     'h26': (26, 26, 256, 512, 3, 1, 'same'),
@@ -31,6 +33,9 @@ def main():
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     N = a.batch
+    for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):      # e.g. YOLO_TUNE=s2_classes=0,wgrad_strip=0
+        k, v = kv.split('=')
+        ops.set_tuning(k, int(v))
     if os.environ.get('YOLO_STRIP'):
         ops.set_tuning('strip_bm', int(os.environ['YOLO_STRIP']))
         ops.set_tuning('strip_bn', int(os.environ.get('YOLO_STRIP_BN', '0')))

@@ -32,7 +32,18 @@ struct Gather {
   int Kg;              // GEMM K = RS * (C0 + C1)
   float rhw, rw;       // 1 / (Ho * Wo), 1 / Wo
   int magicS;          // tap / S == (tap * magicS) >> 16 for tap < 128
+  // ---- stride-2 data gradient as 4 parity classes (blockIdx.y = 2 * (h & 1) + (w & 1) of the output pixel): each class is a dense
+  // stride-1 correlation over dY with 1 or 2 of the 3 taps per dimension, written to every other row / column of dX; the kernel
+  // specialises its copy of this struct per class (s2 == 0: everything below is unused)
+  int s2;
+  int N, S_full;       // images; tap columns of the (flipped) weight tensor
+  int wKg;             // weight row stride in elements (9 * C)
+  struct Dim { int n, pad, size, t0, t1; } rowd[2], cold[2];   // per parity: taps, padding, class grid size, flipped tap indices
+  int OH, OW;          // dX spatial size
 };
+
+// per-launch view of the class a workgroup works on
+struct ClassView { int on, wbase, wdr, wds, two, Hc, Wc, OH, OW, ph, pw; float rhw, rw; };
 
 struct RowInfo { int n, hb, wb; };
 
@@ -104,7 +115,7 @@ constexpr int BK = 64;  // K elements per stage
 template <int BM, int BN, int NW, int WM, int WN, int PT, int CT, bool OUT_F32>
 __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem, int M, int m0, int n0, int tile_m, const float* __restrict__ bias,
                                               void* __restrict__ Yv, int ldy, int accumulate, float* __restrict__ stat_sum,
-                                              float* __restrict__ stat_sq, int Kout, int tid, int lane, int wm, int wn) {
+                                              float* __restrict__ stat_sq, int Kout, int tid, int lane, int wm, int wn, const ClassView& cv) {
   const int cq = (lane >> 4) * 4;
   float ssum[CT][4], ssq[CT][4];
 #pragma unroll
@@ -163,7 +174,14 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
       const int m = m0 + row;
       if (m < M) {
         uint4 v = *reinterpret_cast<const uint4*>(smem + row * OLD + ch * 16);
-        bf16_t* yp = Y + (size_t)m * ldy + n0 + ch * 8;
+        int mo = m;
+        if (cv.on) {                                  // parity class: pixel (n, h', w') of the class grid -> (n, 2h' + ph, 2w' + pw) of dX
+          int n_, rem, hh, ww;
+          fast_divmod(m, cv.Hc * cv.Wc, cv.rhw, n_, rem);
+          fast_divmod(rem, cv.Wc, cv.rw, hh, ww);
+          mo = (n_ * cv.OH + 2 * hh + cv.ph) * cv.OW + 2 * ww + cv.pw;
+        }
+        bf16_t* yp = Y + (size_t)mo * ldy + n0 + ch * 8;
         if (accumulate) {                             // gradient fan-in: y += tile (float32 add, one rounding)
           float a8[8], b8[8];
           unpack_bf8(v, a8);
@@ -226,11 +244,35 @@ __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16
   constexpr int B_INSTR = BN / (8 * NW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  ClassView cv = {};
+  int wKg = g.Kg;
+  if (g.s2) {   // uniform: specialise the gather for this workgroup's parity class
+    const int ph = blockIdx.y >> 1, pw = blockIdx.y & 1;
+    Gather::Dim rd, cd;                        // field-wise selects: no dynamic indexing, no aggregate select (both end up in scratch)
+    rd.n = ph ? g.rowd[1].n : g.rowd[0].n;       cd.n = pw ? g.cold[1].n : g.cold[0].n;
+    rd.pad = ph ? g.rowd[1].pad : g.rowd[0].pad; cd.pad = pw ? g.cold[1].pad : g.cold[0].pad;
+    rd.size = ph ? g.rowd[1].size : g.rowd[0].size; cd.size = pw ? g.cold[1].size : g.cold[0].size;
+    rd.t0 = ph ? g.rowd[1].t0 : g.rowd[0].t0;    cd.t0 = pw ? g.cold[1].t0 : g.cold[0].t0;
+    rd.t1 = ph ? g.rowd[1].t1 : g.rowd[0].t1;    cd.t1 = pw ? g.cold[1].t1 : g.cold[0].t1;
+    wKg = g.wKg;
+    g.S = cd.n; g.RS = rd.n * cd.n; g.pad_h = rd.pad; g.pad_w = cd.pad; g.Ho = rd.size; g.Wo = cd.size;
+    g.M = g.N * rd.size * cd.size; g.Kg = g.RS * g.C1;
+    g.rhw = 1.0f / (float)(rd.size * cd.size); g.rw = 1.0f / (float)cd.size; g.magicS = 65536 / cd.n + 1;
+    cv.on = 1; cv.Hc = rd.size; cv.Wc = cd.size; cv.OH = g.OH; cv.OW = g.OW; cv.ph = ph; cv.pw = pw; cv.rhw = g.rhw; cv.rw = g.rw;
+    // class tap t = r' * S' + s' -> tap of the full (flipped) weight tensor = wbase + r' * wdr + s' * wds (arithmetic, not a table: a
+    // 4-entry select chain is turned into a scratch lookup table by the compiler)
+    cv.two = cd.n == 2;
+    cv.wbase = rd.t0 * g.S_full + cd.t0;
+    cv.wdr = (rd.t1 - rd.t0) * g.S_full;
+    cv.wds = cd.t1 - cd.t0;
+  }
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (m0 >= g.M) return;                     // a smaller parity class has fewer pixel tiles than the grid (whole workgroup, before any barrier)
 
   // LDS-DMA lane geometry: lane -> row (lane >> 3) of the instruction's 8 rows, LDS slot (lane & 7); the slot holds global chunk
   // slot ^ (row & 7) (row & 7 == lane >> 3 because instruction row blocks are 8-aligned)
@@ -260,7 +302,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16
   }
   const bf16_t* wrow[B_INSTR];
 #pragma unroll
-  for (int j = 0; j < B_INSTR; ++j) wrow[j] = Wt + (size_t)(n0 + (wave * B_INSTR + j) * 8 + lrow) * g.Kg + cchunk * 8;
+  for (int j = 0; j < B_INSTR; ++j) wrow[j] = Wt + (size_t)(n0 + (wave * B_INSTR + j) * 8 + lrow) * wKg + cchunk * 8;
 
   f32x4_t acc[CT][PT];
 #pragma unroll
@@ -293,9 +335,16 @@ __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16
         __builtin_amdgcn_global_load_lds((gptr_t)gather_addr(g, rows[j], tr, ts, c, kvalid), (lptr_t)(sA + j * 1024), 16, 0, 0);
     }
     const bool kv = kt * BK + cchunk * 8 < g.Kg;
+    int wk = kt * BK;
+    if (cv.on) {                              // class tap -> tap of the full weight tensor (a K-step never straddles taps: C1 % 64 == 0)
+      const int lgC = g.lgC8 + 3, t = wk >> lgC;
+      const int r1 = cv.two ? t >> 1 : t, s1 = cv.two ? t & 1 : 0;
+      const int wt = cv.wbase + r1 * cv.wdr + s1 * cv.wds;
+      wk = wt * g.C1 + (wk - (t << lgC));
+    }
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(kv ? wrow[j] + kt * BK : reinterpret_cast<const bf16_t*>(&g_zero16)), (lptr_t)(sB + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(kv ? wrow[j] + wk : reinterpret_cast<const bf16_t*>(&g_zero16)), (lptr_t)(sB + j * 1024), 16, 0, 0);
   };
   auto compute_stage = [&](int buf) {
     const char* sA = smem + buf * STAGE;
@@ -330,7 +379,8 @@ __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16
     compute_stage(kt % NSTAGE);
   }
 
-  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, OUT_F32>(acc, smem, g.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane, wm, wn);
+  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, OUT_F32>(acc, smem, g.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane, wm, wn,
+                                                     cv);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -470,8 +520,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, con
       }
   }
   __syncthreads();   // all waves are done with strip / ring before the epilogue reuses the LDS (tile_epilogue syncs only for bf16 outputs)
+  const ClassView cv = {};
   tile_epilogue<BM, BN, NW, WM, WN, PT, CT, false>(acc, smem, a.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane,
-                                                   wm, wn);
+                                                   wm, wn, cv);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -947,6 +998,7 @@ Gather fwd_gather(const yolo_conv_problem* p, const void* src0, const void* src1
   g.smul = p->stride; g.pad_h = p->pad_t; g.pad_w = p->pad_l; g.den = 1;
   g.M = p->N * p->Ho * p->Wo; g.Kg = p->R * p->S * p->Cin;
   g.rhw = 1.0f / (float)(g.Ho * g.Wo); g.rw = 1.0f / (float)g.Wo; g.magicS = 65536 / g.S + 1;
+  g.s2 = 0; g.N = p->N; g.S_full = p->S; g.wKg = g.Kg; g.OH = p->Ho; g.OW = p->Wo;
   return g;
 }
 
@@ -965,6 +1017,7 @@ TileCfg pick_tile(int M, int Kout) {
 // strip kernel plan: 0 = not eligible, else the pixel tile BM (and the channel tile through *bnp)
 // tuning overrides (yolo_set_tuning): strip_bm = -1 auto, 0 = never use the strip kernel, 64 / 128 / 256 = force; strip_bn = 0 auto
 int g_strip_bm = -1, g_strip_bn = 0;
+int g_s2_classes = 1;    // "s2_classes" = 0 keeps the stride-2 data gradient on the strided (den = 2) gather
 int g_wgrad_strip = 1;   // "wgrad_strip" = 0 keeps the weight gradient of 3x3 stride-1 layers on the generic kernel
 int pick_strip(const Gather& g, int Kout, bool f32, int* bnp = nullptr) {
   if (f32 || g.den != 1 || g.C0 != 0 || g.S != 3 || g.RS != 9 || g.smul != 1 || g.pad_h != 1 || g.pad_w != 1) return 0;
@@ -1033,7 +1086,7 @@ int launch_tile3(const Gather& g, const void* w, const float* bias, void* y, int
     if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW>), dim3(tiles_m * tn), dim3(NW * 64), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
+  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW>), dim3(tiles_m * tn, g.s2 ? 4 : 1), dim3(NW * 64), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
                      ssum, ssq, Kout, tn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
@@ -1090,6 +1143,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   if (!strcmp(name, "strip_bm")) { YOLO_CHECK_ARG(value == -1 || value == 0 || value == 64 || value == 128 || value == 256, "strip_bm"); g_strip_bm = value; }
   else if (!strcmp(name, "wgrad_strip")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_strip"); g_wgrad_strip = value; }
   else if (!strcmp(name, "bn_fused_min_chunks")) { YOLO_CHECK_ARG(value >= 1 && value <= 12, "bn_fused_min_chunks"); g_fused_min_chunks = value; }
+  else if (!strcmp(name, "s2_classes")) { YOLO_CHECK_ARG(value == 0 || value == 1, "s2_classes"); g_s2_classes = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
   return YOLO_OK;
@@ -1131,7 +1185,30 @@ extern "C" int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, con
   g.smul = 1; g.pad_h = p->R - 1 - p->pad_t; g.pad_w = p->S - 1 - p->pad_l; g.den = p->stride;
   g.M = p->N * p->H * p->W; g.Kg = p->R * p->S * p->Cout;
   g.rhw = 1.0f / (float)(g.Ho * g.Wo); g.rw = 1.0f / (float)g.Wo; g.magicS = 65536 / g.S + 1;
+  g.s2 = 0; g.N = p->N; g.S_full = p->S; g.wKg = g.Kg; g.OH = p->H; g.OW = p->W;
   YOLO_CHECK_ARG(g.M < (1 << 24), "row decode needs N*H*W < 2^24");
+  if (g_s2_classes && p->stride == 2 && p->R == 3 && p->S == 3 && p->H >= 2 && p->W >= 2 && p->Cout % 64 == 0) {
+    // dX[h] = sum_r dY[(h + pad - r) / 2] W[r] over the r with (h + pad - r) even: for h = 2h' + ph the taps r = (ph + pad) mod 2 (+ 2),
+    // taken in descending r (= ascending flipped index R-1-r) they read dY rows h' - pad', h' - pad' + 1: a stride-1 correlation.
+    // The strided gather (den = 2) instead walks all 9 taps and fetches zeros for 27 of every 36 (pixel, tap) pairs.
+    auto dim = [](int pad, int size, Gather::Dim (&d)[2]) {
+      for (int par = 0; par < 2; ++par) {
+        const int r_lo = (par + pad) & 1;                // taps r_lo, r_lo + 2 (< 3)
+        const int r_hi = r_lo + 2 < 3 ? r_lo + 2 : r_lo;
+        d[par].n = r_hi > r_lo ? 2 : 1;
+        d[par].t0 = 2 - r_hi;                            // flipped index of the first (largest r) tap
+        d[par].t1 = 2 - r_lo;
+        d[par].pad = -((par + pad - r_hi) / 2);          // (par + pad - r_hi) is even and <= 0
+        d[par].size = (size - par + 1) / 2;
+      }
+    };
+    dim(p->pad_t, p->H, g.rowd);
+    dim(p->pad_l, p->W, g.cold);
+    g.s2 = 1;
+    g.wKg = g.Kg;
+    g.M = p->N * g.rowd[0].size * g.cold[0].size;        // the largest class: tile choice and grid size
+    g.den = 1;
+  }
   return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate, nullptr, nullptr, p->Cin, (hipStream_t)stream);
 }
 
