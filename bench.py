@@ -62,26 +62,29 @@ def build_model(backbone, H, W, N, class_num, device):
 
 
 def conv_kernel_roofline(model, steps):
-    """Average achieved TFLOP/s of the dominant kernel (the implicit-GEMM fwd/dgrad kernel) measured with HIP events on the
-    launch stream in an eager (non-graph) pass: sum of algorithmic FLOPs of its launches / sum of their durations."""
-    from yolov3_tensorflow_amd import engine, ops
+    """Achieved TFLOP/s of the dominant kernel, conv3x3_strip_kernel (every 3x3 / stride-1 convolution forward and data gradient of the
+    step; the remaining stem / stride-2 / 1x1 launches run igemm_fwd_kernel and are reported beside it), measured with HIP events on
+    the launch stream in an eager pass with the weight-gradient stream folded into the main stream: sum of algorithmic FLOPs of the
+    launches / sum of their durations."""
+    from yolov3_tensorflow_amd import ops
     records = []
 
-    def timed(fn, flops_of):
+    def is_strip(p):
+        return (p.R == 3 and p.S == 3 and p.stride == 1 and p.pad_t == 1 and p.pad_l == 1 and p.C0 == 0 and p.Ho == p.H and p.Wo == p.W
+                and p.Cin % 64 == 0 and p.Cout % 64 == 0)
+
+    def timed(fn):
         def wrapper(p, *a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn(p, *a, **k)
             e1.record()
-            records.append((e0, e1, flops_of(p)))
+            cin = 3 if p.Cin == 8 else p.Cin     # algorithmic: the RGB stem is 3 of the 8 padded channels
+            records.append((e0, e1, 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S, is_strip(p) and k.get('bias') is None))
         return wrapper
 
-    def flops(p):     # algorithmic: real (unpadded) channels are within 0.4 % of the padded ones except the RGB stem (3 of 8)
-        cin = 3 if p.Cin == 8 else p.Cin
-        return 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S
-
     ops_fwd, ops_dg = ops.conv2d_fwd, ops.conv2d_dgrad
-    ops.conv2d_fwd, ops.conv2d_dgrad = timed(ops_fwd, flops), timed(ops_dg, flops)
+    ops.conv2d_fwd, ops.conv2d_dgrad = timed(ops_fwd), timed(ops_dg)
     saved = model.overlap_wgrad
     model.overlap_wgrad = False        # time each launch alone on the stream (no weight-gradient GEMM sharing the CUs)
     try:
@@ -92,9 +95,13 @@ def conv_kernel_roofline(model, steps):
     finally:
         ops.conv2d_fwd, ops.conv2d_dgrad = ops_fwd, ops_dg
         model.overlap_wgrad = saved
-    t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in records)
-    fl = sum(f for _, _, f in records)
-    return fl / (t_ms * 1e-3) / 1e12, t_ms / max(len(records), 1), len(records) // max(steps, 1)
+    out = {}
+    for name, sel in (('strip', True), ('other', False)):
+        rs = [r for r in records if r[3] == sel]
+        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rs)
+        fl = sum(r[2] for r in rs)
+        out[name] = (fl / (t_ms * 1e-3) / 1e12 if rs else 0.0, t_ms / max(len(rs), 1), len(rs) // max(steps, 1))
+    return out
 
 
 def cpu_baseline(H, W, class_num, budget_batch=4):
@@ -200,10 +207,14 @@ def main():
         out['step_tflops'] = round(ips / world * gflop / 1000.0, 2)      # per GPU, whole step, algorithmic conv FLOPs
         out['step_mfma_frac'] = round(out['step_tflops'] / PEAK_BF16_TFLOPS, 4)
     if rank == 0 and not args.no_roofline:
-        tf, avg_ms, per_step = conv_kernel_roofline(model, max(2, min(5, args.steps)))
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'igemm_fwd_kernel (conv forward + data-gradient launches)', 'achieved': round(tf, 2),
-                           'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-                           'avg_launch_ms': round(avg_ms, 5), 'launches_per_step': per_step}
+        rf = conv_kernel_roofline(model, max(2, min(5, args.steps)))
+        tf, avg_ms, per_step = rf['strip']
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel (3x3 stride-1 conv forward + data-gradient launches, all tile variants)',
+                           'achieved': round(tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_TFLOPS, 4),
+                           'traffic': None, 'avg_launch_ms': round(avg_ms, 5), 'launches_per_step': per_step,
+                           'other_conv': {'kernel': 'igemm_fwd_kernel (stem, stride-2, 1x1, fused-concat launches)',
+                                          'achieved': round(rf['other'][0], 2), 'avg_launch_ms': round(rf['other'][1], 5),
+                                          'launches_per_step': rf['other'][2]}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(H, W, args.classes)
     if rank == 0:
