@@ -415,6 +415,95 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf
   }
 }
 
+// Stem backward apply, tiled: dy[pre-pool] = a (g - k1 - xhat k2) with g = the max-pool un-pooling of dout * relu'(out).  A workgroup owns
+// a 16 x 16 pre-pool tile and first stages the <= 10 x 10 pooled pixels whose windows touch it (masked gradient as bf16 + arg-max byte,
+// 3 B per element) in LDS; the per-pixel gather of the 1..4 covering windows then reads LDS.  The grid-stride version above fetched every
+// pooled element up to 9 times from L2 (1.35 GB of L2 traffic at batch 32 / 416^2: 235 us); this one is bound by the y read + dy write.
+constexpr int PT_TILE = 16, PT_POOLED = PT_TILE / 2 + 2;
+__global__ __launch_bounds__(EW_THREADS) void bn_pool_bwd_apply_tiled_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+                                                                              const uint8_t* __restrict__ argmax, int relu,
+                                                                              const bf16_t* __restrict__ y, const float* __restrict__ a1,
+                                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                              const float* __restrict__ k1, const float* __restrict__ k2,
+                                                                              bf16_t* __restrict__ dy, int H, int W, int C, int Ho, int Wo,
+                                                                              int pt, int pl, int tiles_w, int tiles_h) {
+  extern __shared__ __attribute__((aligned(16))) char pool_smem[];
+  const int CV = C >> 3;
+  uint4* sG = reinterpret_cast<uint4*>(pool_smem);                                           // [PT_POOLED^2][CV] masked gradient, bf16 x 8
+  uint2* sA = reinterpret_cast<uint2*>(pool_smem + (size_t)PT_POOLED * PT_POOLED * CV * 16);   // [PT_POOLED^2][CV] arg-max codes, 8 bytes
+  int b = blockIdx.x;
+  const int tw = b % tiles_w; b /= tiles_w;
+  const int th = b % tiles_h;
+  const int n = b / tiles_h;
+  const int h0 = th * PT_TILE, w0 = tw * PT_TILE;
+  // first pooled row / column whose window can touch the tile: 2 ho - pt + 2 >= h0
+  const int ho0 = max(0, (h0 + pt - 1) >> 1), wo0 = max(0, (w0 + pl - 1) >> 1);
+  for (int i = threadIdx.x; i < PT_POOLED * PT_POOLED * CV; i += EW_THREADS) {
+    const int cv = i % CV, pp = i / CV;
+    const int ho = ho0 + pp / PT_POOLED, wo = wo0 + pp % PT_POOLED;
+    uint4 g = make_uint4(0u, 0u, 0u, 0u);
+    uint2 am = make_uint2(0xffffffffu, 0xffffffffu);
+    if (ho < Ho && wo < Wo) {
+      const size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * 8;
+      g = ld16(dout + o);
+      am = *reinterpret_cast<const uint2*>(argmax + o);
+      if (relu) {
+        const uint4 ov = ld16(out + o);
+        const unsigned ow[4] = {ov.x, ov.y, ov.z, ov.w};
+        unsigned gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned lo = ow[q] & 0xffffu, hi = ow[q] >> 16;
+          gw[q] = ((lo != 0u && lo < 0x8000u) ? (gw[q] & 0xffffu) : 0u) | ((hi != 0u && hi < 0x8000u) ? (gw[q] & 0xffff0000u) : 0u);
+        }
+        g = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+      }
+    }
+    sG[i] = g;
+    sA[i] = am;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PT_TILE * PT_TILE * CV; i += EW_THREADS) {
+    const int cv = i % CV, pix = i / CV;
+    const int h = h0 + pix / PT_TILE, w = w0 + pix % PT_TILE;
+    if (h >= H || w >= W) continue;
+    const int c = cv * 8;
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hn = h + pt - dh;
+      if (hn < 0 || (hn & 1)) continue;
+      const int ho = hn >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wn = w + pl - dw;
+        if (wn < 0 || (wn & 1)) continue;
+        const int wo = wn >> 1;
+        if (wo >= Wo) continue;
+        const int li = ((ho - ho0) * PT_POOLED + (wo - wo0)) * CV + cv;
+        const uint2 a = sA[li];
+        float d[8];
+        unpack_bf8(sG[li], d);
+        const int code = dh * 3 + dw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int aj = (j < 4 ? (a.x >> (8 * j)) : (a.y >> (8 * (j - 4)))) & 0xff;
+          if (aj == code) g[j] += d[j];
+        }
+      }
+    }
+    const size_t o = ((size_t)(n * H + h) * W + w) * C + c;
+    float v[8], r[8];
+    unpack_bf8(ld16(y + o), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a1[c + j] * (g[j] - k1[c + j] - (v[j] - mean[c + j]) * rstd[c + j] * k2[c + j]);
+    st16(dy + o, pack_bf8(r));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // BatchNorm(+ReLU, + residual / second BN branch) backward in ONE launch: reduce, finalize and apply of the three-kernel path above.
 // ------------------------------------------------------------------------------------------------------------------
@@ -892,6 +981,15 @@ extern "C" int yolo_bn_pool_bwd_apply(const void* dout, const void* out, const u
   if (rc) return rc;
   YOLO_CHECK_ARG(dy, "null dy");
   YOLO_CHECK_ARG(!a1 || (y && mean && rstd && k1 && k2), "BN branch incomplete");
+  const size_t pool_lds = (size_t)PT_POOLED * PT_POOLED * (C / 8) * 24;
+  if (a1 && pad_t >= 0 && pad_t <= 1 && pad_l >= 0 && pad_l <= 1 && pool_lds <= 64 * 1024) {
+    const int tiles_h = (H + PT_TILE - 1) / PT_TILE, tiles_w = (W + PT_TILE - 1) / PT_TILE;
+    hipLaunchKernelGGL(bn_pool_bwd_apply_tiled_kernel, dim3(N * tiles_h * tiles_w), dim3(EW_THREADS), pool_lds, (hipStream_t)stream,
+                       (const bf16_t*)dout, (const bf16_t*)out, argmax, relu, (const bf16_t*)y, a1, mean, rstd, k1, k2, (bf16_t*)dy, H, W, C,
+                       Ho, Wo, pad_t, pad_l, tiles_w, tiles_h);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+  }
   const size_t M = (size_t)N * H * W;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<PoolGrad>, dim3(ew_grid(M * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream, gp,
                      (const bf16_t*)y, a1, mean, rstd, k1, k2, (bf16_t*)dy, 0, (const bf16_t*)nullptr, (const float*)nullptr,
