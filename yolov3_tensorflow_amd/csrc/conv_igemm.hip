@@ -1017,6 +1017,9 @@ TileCfg pick_tile(int M, int Kout) {
 // strip kernel plan: 0 = not eligible, else the pixel tile BM (and the channel tile through *bnp)
 // tuning overrides (yolo_set_tuning): strip_bm = -1 auto, 0 = never use the strip kernel, 64 / 128 / 256 = force; strip_bn = 0 auto
 int g_strip_bm = -1, g_strip_bn = 0;
+// workgroups aimed at by the two-phase path: 1.5 per CU measured best on the whole step (256 / 384 / 512 tried: fewer slabs to sum
+// and less competition with the main stream's kernels outweigh the shorter pixel ranges of 512)
+int g_wgrad_target = 384;   // "wgrad_target" tuning
 int g_s2_classes = 1;    // "s2_classes" = 0 keeps the stride-2 data gradient on the strided (den = 2) gather
 int g_wgrad_strip = 1;   // "wgrad_strip" = 0 keeps the weight gradient of 3x3 stride-1 layers on the generic kernel
 int pick_strip(const Gather& g, int Kout, bool f32, int* bnp = nullptr) {
@@ -1144,6 +1147,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "wgrad_strip")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_strip"); g_wgrad_strip = value; }
   else if (!strcmp(name, "bn_fused_min_chunks")) { YOLO_CHECK_ARG(value >= 1 && value <= 12, "bn_fused_min_chunks"); g_fused_min_chunks = value; }
   else if (!strcmp(name, "s2_classes")) { YOLO_CHECK_ARG(value == 0 || value == 1, "s2_classes"); g_s2_classes = value; }
+  else if (!strcmp(name, "wgrad_target")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "wgrad_target"); g_wgrad_target = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
   return YOLO_OK;
@@ -1282,9 +1286,6 @@ void launch_wgrad(const yolo_conv_problem* p, const WgradPlan& pl, const void* d
 #undef YOLO_WGRAD_LAUNCH
 }
 
-// workgroups aimed at by the two-phase path: 1.5 per CU measured best on the whole step (256 / 384 / 512 tried: fewer slabs to sum
-// and less competition with the main stream's kernels outweigh the shorter pixel ranges of 512)
-constexpr int kWgradTarget = 384;
 }  // namespace
 
 extern "C" int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
@@ -1301,7 +1302,7 @@ extern "C" int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, c
 extern "C" size_t yolo_conv2d_wgrad_workspace_bytes(const yolo_conv_problem* p) {
   WgradPlan pl;
   static const char dummy = 0;
-  if (!p || plan_wgrad(p, &dummy, &dummy, 0, kWgradTarget, &pl)) return 0;
+  if (!p || plan_wgrad(p, &dummy, &dummy, 0, g_wgrad_target, &pl)) return 0;
   return pl.split_k > 1 ? (size_t)pl.split_k * (size_t)p->Cout * (size_t)pl.g.Kg * sizeof(float) : 0;
 }
 
@@ -1309,7 +1310,7 @@ extern "C" int yolo_conv2d_wgrad_reduce(const yolo_conv_problem* p, const void* 
                                         void* workspace, size_t workspace_bytes, int accumulate, void* stream) {
   YOLO_CHECK_ARG(p && src1 && dy && dw, "null pointer");
   WgradPlan pl;
-  int rc = plan_wgrad(p, src0, src1, 0, kWgradTarget, &pl);
+  int rc = plan_wgrad(p, src0, src1, 0, g_wgrad_target, &pl);
   if (rc) return rc;
   const size_t n = (size_t)p->Cout * (size_t)pl.g.Kg;
   if (pl.split_k == 1) {                              // one workgroup per tile: straight into dw (plain stores, or atomics to add)

@@ -168,6 +168,7 @@ class Graph(object):
         self.dev = device
         self.ps = ParamStore(seed)
         self.tape = []
+        self._repack_event = None
         self.fused_bn_bwd = True         # single-launch BatchNorm backward where the tensor fits (ops.bn_act_bwd_fused)
         self.vals = []
         self.bns = []            # every keras BatchNormalization (for checkpoints)
@@ -408,12 +409,25 @@ class Graph(object):
         event after its dY is complete, joined once at the end): the MFMA-bound wgrads then overlap the bandwidth-bound BatchNorm
         backward kernels and the tails of the data-gradient GEMMs.  Under hipGraph capture this becomes a forked graph."""
         side = self.wgrad_stream
+        if self._repack_event is not None:        # the data-gradient weight copies were refreshed on the side stream (refresh_dgrad_async)
+            torch.cuda.current_stream(self.dev).wait_event(self._repack_event)
+            self._repack_event = None
         for i, f in enumerate(self.bwd):
             f()
             if i == self.bucket_cut and self.on_bucket is not None:
                 self.on_bucket()          # every gradient of the late-layer bucket has been enqueued (main + wgrad stream)
         if side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(side)
+
+    def refresh_dgrad_async(self):
+        """refresh_dgrad_weights on the weight-gradient stream (eager mode): the copies are first needed by the NEXT step's backward pass,
+        so the repack overlaps the next forward instead of sitting between the optimizer and it"""
+        if self.wgrad_stream is None:
+            self.refresh_dgrad_weights()
+            return
+        self.on_wgrad_stream(self.refresh_dgrad_weights)
+        self._repack_event = torch.cuda.Event()
+        self._repack_event.record(self.wgrad_stream)
 
     def on_wgrad_stream(self, fn):
         """run fn() on the weight-gradient stream after everything enqueued so far on the current stream"""

@@ -87,7 +87,10 @@ class YOLOv3Model(object):
     def _update(self):
         g = self.g
         self.optimizer.launch(self)
-        g.refresh_dgrad_weights()
+        if self.use_hip_graph:
+            g.refresh_dgrad_weights()
+        else:
+            g.refresh_dgrad_async()
 
     def _capture(self):
         if not self.use_hip_graph:
