@@ -401,7 +401,7 @@ struct StripArgs {
   float rhw, rw;
 };
 
-template <int BM, int BN, int NW>
+template <int BM, int BN, int NW, int WS>
 __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, const float* __restrict__ bias, void* __restrict__ Yv, int ldy,
                                                             int accumulate, float* __restrict__ stat_sum, float* __restrict__ stat_sq,
                                                             int Kout, int tiles_n) {
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, con
   constexpr int CT = BN / WN / 16;
   constexpr int B_INSTR = BN / (8 * NW);   // weight LDS-DMA instructions per wave per k-step (8 rows x 128 B each)
   constexpr int W_STAGE = BN * 128;
+  static_assert(WS == 2 || WS == 3, "weight ring depth");
   static_assert(B_INSTR >= 1, "tile too small for the wave count");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sStrip = smem;
@@ -502,21 +503,31 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, con
     }
   };
 
-  issue_weights(0, 0, 0);
-  int kk = 0;
+  // weight ring of WS stages: the tiles of K-steps kk+1 .. kk+WS-1 are in flight while K-step kk is computed (WS = 3 where the LDS
+  // budget keeps the same number of workgroups per CU: one K-step of compute is shorter than an L2 round trip)
+  int icc = 0, itap = 0, istage = 0;                       // next (slice, tap) to issue and its ring stage
+  auto issue_next = [&]() {
+    issue_weights(icc, itap, istage);
+    if (++itap == 9) { itap = 0; ++icc; }
+    if (++istage == WS) istage = 0;
+  };
+#pragma unroll
+  for (int q = 0; q < WS - 1; ++q)
+    if (q < nk) issue_next();
+  int kk = 0, cstage = 0;
   for (int cc = 0; cc < nchunk; ++cc) {
     if (cc > 0) __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous slice's strip
     issue_strip(cc);
     for (int tr = 0; tr < 3; ++tr)
       for (int ts = 0; ts < 3; ++ts, ++kk) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                  // strip + weight stage kk visible; weight stage kk-1 no longer read
+        // weight stage kk (and, on the first tap of a slice, the strip issued after the prefetched stages) must have landed
+        if (WS == 2 || (tr | ts) == 0 || kk + WS - 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else                                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WS - 2) * B_INSTR) : "memory");
+        __builtin_amdgcn_s_barrier();                  // strip + weight stage kk visible; the stage of K-step kk-1 is no longer read
         asm volatile("" ::: "memory");
-        if (kk + 1 < nk) {
-          const int t1 = tr * 3 + ts + 1;
-          issue_weights(t1 == 9 ? cc + 1 : cc, t1 == 9 ? 0 : t1, (kk + 1) & 1);
-        }
-        compute(tr, ts, kk & 1);
+        if (kk + WS - 1 < nk) issue_next();
+        compute(tr, ts, cstage);
+        if (++cstage == WS) cstage = 0;
       }
   }
   __syncthreads();   // all waves are done with strip / ring before the epilogue reuses the LDS (tile_epilogue syncs only for bf16 outputs)
@@ -1017,6 +1028,7 @@ TileCfg pick_tile(int M, int Kout) {
 // strip kernel plan: 0 = not eligible, else the pixel tile BM (and the channel tile through *bnp)
 // tuning overrides (yolo_set_tuning): strip_bm = -1 auto, 0 = never use the strip kernel, 64 / 128 / 256 = force; strip_bn = 0 auto
 int g_strip_bm = -1, g_strip_bn = 0;
+int g_strip_ws = 0;      // "strip_ws": 0 auto, 2 / 3 force the weight-ring depth of the strip kernel
 // workgroups aimed at by the two-phase path: 1.5 per CU measured best on the whole step (256 / 384 / 512 tried: fewer slabs to sum
 // and less competition with the main stream's kernels outweigh the shorter pixel ranges of 512)
 int g_wgrad_target = 384;   // "wgrad_target" tuning
@@ -1050,8 +1062,8 @@ int stat_rows_for(const Gather& g, int Kout) {
   return (g.M + t.bm - 1) / t.bm;      // one partial row per pixel tile
 }
 
-template <int BM, int BN, int NW>
-int launch_strip(const Gather& g, const void* w, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout, hipStream_t st) {
+template <int BM, int BN, int NW, int WS>
+int launch_strip_ws(const Gather& g, const void* w, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout, hipStream_t st) {
   StripArgs a;
   a.src = g.src1;
   a.src_bytes = (unsigned)((size_t)g.M / ((size_t)g.Ho * g.Wo) * g.Hs * g.Ws * g.C1 * 2);
@@ -1060,20 +1072,32 @@ int launch_strip(const Gather& g, const void* w, void* y, int ldy, int accumulat
   a.H = g.Ho; a.W = g.Wo; a.C = g.C1; a.M = g.M; a.Kg = g.Kg;
   a.E8 = (BM + 2 * g.Wo + 2 + 7) / 8 * 8;
   a.rhw = g.rhw; a.rw = g.rw;
-  const size_t lds_main = (size_t)a.E8 * 128 + 128 + 2 * (size_t)BN * 128, lds_out = (size_t)BM * (BN * 2 + 16);
+  const size_t lds_main = (size_t)a.E8 * 128 + 128 + WS * (size_t)BN * 128, lds_out = (size_t)BM * (BN * 2 + 16);
   const size_t lds = lds_main > lds_out ? lds_main : lds_out;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<BM, BN, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<BM, BN, NW, WS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
-  hipLaunchKernelGGL((conv3x3_strip_kernel<BM, BN, NW>), dim3(tiles_m * tn), dim3(NW * 64), lds, st, a, nullptr, y, ldy, accumulate, ssum, ssq,
+  hipLaunchKernelGGL((conv3x3_strip_kernel<BM, BN, NW, WS>), dim3(tiles_m * tn), dim3(NW * 64), lds, st, a, nullptr, y, ldy, accumulate, ssum, ssq,
                      Kout, tn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
+}
+
+// third weight stage where three workgroups per CU still fit in the 160 KiB of LDS (measured: +7..14 % on the 26 x 26 / 13 x 13 maps,
+// -25 % where it drops the 104 x 104 maps to one workgroup per CU)
+template <int BM, int BN, int NW>
+int launch_strip(const Gather& g, const void* w, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout, hipStream_t st) {
+  const size_t strip = (size_t)((BM + 2 * g.Wo + 2 + 7) / 8 * 8) * 128 + 128, out = (size_t)BM * (BN * 2 + 16);
+  auto lds = [&](int ws) { const size_t m = strip + (size_t)ws * BN * 128; return m > out ? m : out; };
+  const size_t cap = 160 * 1024;
+  if (g_strip_ws != 2 && (g_strip_ws == 3 || cap / lds(3) >= 3) && lds(3) <= cap)
+    return launch_strip_ws<BM, BN, NW, 3>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
+  return launch_strip_ws<BM, BN, NW, 2>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
 }
 
 template <int BM, int BN, int NS, bool F32, bool FAST, int NW>
@@ -1148,6 +1172,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "bn_fused_min_chunks")) { YOLO_CHECK_ARG(value >= 1 && value <= 12, "bn_fused_min_chunks"); g_fused_min_chunks = value; }
   else if (!strcmp(name, "s2_classes")) { YOLO_CHECK_ARG(value == 0 || value == 1, "s2_classes"); g_s2_classes = value; }
   else if (!strcmp(name, "wgrad_target")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "wgrad_target"); g_wgrad_target = value; }
+  else if (!strcmp(name, "strip_ws")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 3, "strip_ws"); g_strip_ws = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
   return YOLO_OK;
