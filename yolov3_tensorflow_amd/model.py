@@ -72,6 +72,11 @@ class YOLOv3Model(object):
     def set_distributed(self, world_size, rank, process_group=None):
         self.world_size, self.rank, self.process_group = world_size, rank, process_group
         self._graphs = None
+        if world_size > 1:
+            # the single-launch BatchNorm backward needs its whole grid resident (one 1024-thread, ~120-VGPR workgroup on every CU); an
+            # RCCL kernel of the overlapped gradient all-reduce holds registers on some CUs for the length of the collective, so the
+            # grid barrier would wait for it: data-parallel runs keep the three-kernel path
+            self.g.fused_bn_bwd = False
 
     # ---------------------------------------------------------------------------------------------- step
     def _fwd_bwd(self):
