@@ -44,6 +44,9 @@ CONV_CASES = [
     (2, 10, 14, 64, 128, 1, 2, 'valid'),    # NIN shortcut
     (2, 16, 16, 8, 64, 3, 2, 'same'),       # stem (RGB padded to 8 channels), K = 72 not a multiple of 64
     (1, 7, 7, 512, 256, 3, 1, 'same'),
+    (2, 1, 1, 64, 64, 3, 1, 'same'),        # degenerate maps: every tap but the centre is padding
+    (3, 2, 5, 64, 128, 3, 1, 'same'),
+    (2, 3, 2, 64, 64, 3, 2, 'same'),
     # large enough for the LDS-resident strip kernel (3x3 / stride 1): 128- and 256-pixel tiles, 64 / 128 wide, strips that span several
     # images (13 x 13), two 64-channel slices, non-square maps
     (128, 13, 13, 64, 512, 3, 1, 'same'),
