@@ -147,7 +147,8 @@ int yolo_pack_input(const float* images, void* out, int64_t npix, int Cimg, void
  * Mixed depthwise convolution of MixNet-18: channel groups split[g]..split[g+1] use a ksize[g] x ksize[g] depthwise kernel
  * (stride 1, 'same').  Replaces the Lambda slices + 4 DepthwiseConv2D + Concatenate of /root/reference/backbone/mixnet18.py:38-45
  * (factory /root/reference/backbone/basic_backbone.py:45-66) and their TF gradients.  x, y: bf16 [N,H,W,C]; w_g: bf16
- * [k][k][C_g]; dw_g: float32, atomically accumulated.
+ * [k][k][C_g]; dw_g: float32 = (accumulate ? dw_g : 0) + gradient; the weight gradient is two-phase (per-workgroup slabs in `workspace`,
+ * >= yolo_dwconv_mix_wgrad_workspace_bytes(p) bytes, then one summing launch): deterministic, no atomics.
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct {
   int32_t N, H, W, C;
@@ -158,8 +159,9 @@ int yolo_dwconv_mix_fwd(const yolo_mixconv_problem* p, const void* x, const void
                         void* y, void* stream);
 int yolo_dwconv_mix_dgrad(const yolo_mixconv_problem* p, const void* dy, const void* w0, const void* w1, const void* w2, const void* w3,
                           void* dx, int accumulate, void* stream);
+size_t yolo_dwconv_mix_wgrad_workspace_bytes(const yolo_mixconv_problem* p);
 int yolo_dwconv_mix_wgrad(const yolo_mixconv_problem* p, const void* x, const void* dy, float* dw0, float* dw1, float* dw2, float* dw3,
-                          void* stream);
+                          void* workspace, size_t workspace_bytes, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * YOLOv3 loss forward + backward.  Replaces YOLOv3Decoder.decode (/root/reference/yolov3/yolov3_decoder.py:62-192),

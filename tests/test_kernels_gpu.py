@@ -455,12 +455,12 @@ def test_bn_pool_relu_fwd_bwd(dev):
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize('f', [64, 128])
-def test_mixconv_fwd_dgrad_wgrad(dev, f):
-    """mixed depthwise conv (mixnet18.py:38-45) vs 4 x F.conv2d(groups=C_g) on channel slices"""
+@pytest.mark.parametrize('f,N,H,W', [(64, 2, 11, 9), (128, 2, 11, 9), (64, 3, 40, 104), (512, 5, 13, 13), (256, 2, 26, 26), (64, 1, 3, 2)])
+def test_mixconv_fwd_dgrad_wgrad(dev, f, N, H, W):
+    """mixed depthwise conv (mixnet18.py:38-45) vs 4 x F.conv2d(groups=C_g) on channel slices: ragged strips, several row tiles per
+    image (W = 104), 1 / 2 / 4 chunks per workgroup, maps smaller than the largest kernel"""
     from yolov3_tensorflow_amd import ops
     g = torch.Generator().manual_seed(21)
-    N, H, W = 2, 11, 9
     split = [0, f // 2, 3 * f // 4, 7 * f // 8, f]
     ks = [3, 5, 7, 9]
     x = bf(torch.randn(N, H, W, f, generator=g))
@@ -484,10 +484,14 @@ def test_mixconv_fwd_dgrad_wgrad(dev, f):
     dx = torch.full((N, H, W, f), 0.5, dtype=torch.bfloat16, device=dev)
     ops.dwconv_mix_dgrad(p, d(dy), wd, dx, accumulate=True)
     torch.testing.assert_close(dx.float().cpu(), xr.grad + 0.5, rtol=1e-2, atol=2e-2)
-    dw = [torch.zeros(k, k, split[i + 1] - split[i], device=dev) for i, k in enumerate(ks)]
-    ops.dwconv_mix_wgrad(p, d(x), d(dy), dw)
+    dw = [torch.full((k, k, split[i + 1] - split[i]), 3.0, device=dev) for i, k in enumerate(ks)]
+    wsp = torch.empty(max(ops.dwconv_mix_wgrad_workspace_bytes(p), 16) // 4, device=dev)
+    ops.dwconv_mix_wgrad(p, d(x), d(dy), dw, wsp)                      # overwrites
     for a, b in zip(dw, wr):
-        torch.testing.assert_close(a.cpu(), b.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(a.cpu(), b.grad, rtol=1e-3, atol=1e-3 * max(1.0, b.grad.abs().max().item()))
+    ops.dwconv_mix_wgrad(p, d(x), d(dy), dw, wsp, accumulate=True)
+    for a, b in zip(dw, wr):
+        torch.testing.assert_close(a.cpu(), 2 * b.grad, rtol=1e-3, atol=2e-3 * max(1.0, b.grad.abs().max().item()))
 
 
 def test_pack_input(dev):

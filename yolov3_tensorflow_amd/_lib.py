@@ -68,7 +68,8 @@ SIGNATURES = {
     'yolo_bn_eval_scale_shift': (I, [P, P, P, P, F, P, P, I, P]),
     'yolo_dwconv_mix_fwd': (I, [MP, P, P, P, P, P, P, P]),
     'yolo_dwconv_mix_dgrad': (I, [MP, P, P, P, P, P, P, I, P]),
-    'yolo_dwconv_mix_wgrad': (I, [MP, P, P, P, P, P, P, P]),
+    'yolo_dwconv_mix_wgrad_workspace_bytes': (C.c_size_t, [MP]),
+    'yolo_dwconv_mix_wgrad': (I, [MP, P, P, P, P, P, P, P, C.c_size_t, I, P]),
     'yolo_loss_workspace_bytes': (I64, [LP, I]),
     'yolo_loss_fwd_bwd': (I, [LP, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'yolo_decode_head': (I, [P, I, I, I, I, I, I, P, F, P, P, P, P, P]),

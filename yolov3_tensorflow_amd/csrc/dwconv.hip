@@ -24,64 +24,110 @@ __device__ __forceinline__ uint4 ld16(const bf16_t* p) { return *reinterpret_cas
 
 constexpr int SP = 8;   // output pixels per lane (a horizontal strip)
 
-// fwd / dgrad body for one kernel size: a lane owns a strip of SP consecutive output pixels of one image row and 8 channels; per kernel
-// row it loads the SP + K - 1 input chunks and the K weight chunks once and slides the window in registers (K*(SP+K-1)/SP loads per
-// output instead of K*K).
+// Both kernels work on LDS-resident row tiles: a workgroup stages TH (+ K - 1 halo) image rows of cvb 8-channel chunks, zero-padded to
+// [-K/2, 8*strips + K/2) columns, as 16-byte chunks [row][column][chunk] with a row pitch == cvb (mod 16) chunks, so that lanes that
+// differ in (row, chunk) hit different bank quads.  The first version read every input chunk K*(SP+K-1)/SP times from global memory
+// (18x for K = 9) and, in the weight gradient, made one pass over the data per kernel row with an 81-round serial block reduction:
+// 100 / 490 us per launch on the 104 x 104 map against ~25 us of HBM time.
+struct TilePlan { int TH, cvb, xpitch, W8, nsub, per_sub; };   // rows per tile, chunks per workgroup, x row pitch (chunks), 8*strips,
+                                                                // channel sub-blocks of the group, workgroups per sub-block
+
+__host__ __device__ inline TilePlan plan_tile(int H, int W, int K, int cv, int blocks) {
+  TilePlan t;
+  t.W8 = (W + SP - 1) / SP * SP;
+  t.cvb = t.W8 <= 32 ? (cv < 4 ? cv : 4) : (t.W8 <= 64 ? (cv < 2 ? cv : 2) : 1);
+  const int wp = (t.W8 + K - 1) * t.cvb;
+  t.xpitch = (wp + 15) / 16 * 16 + t.cvb;
+  const int budget = 4096;                                   // 64 KiB of 16-byte chunks for x + dy / x alone
+  int th = (budget - (K - 1) * t.xpitch) / (t.W8 * t.cvb + t.xpitch);
+  t.TH = th < 1 ? 1 : (th > H ? H : th);
+  t.nsub = cv / t.cvb;
+  t.per_sub = blocks / t.nsub < 1 ? 1 : blocks / t.nsub;
+  return t;
+}
+
+__device__ __forceinline__ void stage_rows(uint4* dst, int pitch, const bf16_t* __restrict__ src, int n, int h_first, int nrows, int col_first,
+                                           int ncols, int H, int W, int C, int c, int cvb) {
+  // dst[row][col][cb] = src[n][h_first + row][col_first + col][c + 8 cb .. +7], zeros outside the image
+  const int total = nrows * ncols * cvb;
+  for (int i = threadIdx.x; i < total; i += DW_THREADS) {
+    const int cb = i % cvb;
+    int t = i / cvb;
+    const int col = t % ncols, row = t / ncols;
+    const int h = h_first + row, w = col_first + col;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (h >= 0 && h < H && w >= 0 && w < W) v = ld16(src + ((size_t)(n * H + h) * W + w) * C + c + cb * 8);
+    dst[row * pitch + col * cvb + cb] = v;
+  }
+}
+
+// fwd / dgrad for one kernel size: lane = (row, strip of SP pixels, chunk); per kernel row it reads the SP + K - 1 input chunks of its
+// strip from LDS once and slides the window in registers.  dgrad is the same kernel with flipped taps (stride 1, symmetric padding).
 template <int K>
-__device__ __forceinline__ void dw_strip(const MixP& p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
-                                         int c0, int cg, int cv, int flip, int accumulate) {
+__device__ __forceinline__ void dw_tile(const MixP& p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                        int c0, int cg, int cv, int flip, int accumulate, uint4* smem) {
   constexpr int PAD = K / 2;
-  const int strips = (p.W + SP - 1) / SP;
-  const size_t total = (size_t)p.N * p.H * strips * cv;
-  for (size_t i = (size_t)blockIdx.x * DW_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * DW_THREADS) {
-    const int chunk = (int)(i % cv);
-    size_t t = i / cv;
-    const int sx = (int)(t % strips);
-    t /= strips;
-    const int hq = (int)(t % p.H);
-    const int n = (int)(t / p.H);
-    const int c = c0 + chunk * 8, w0 = sx * SP;
-    float acc[SP][8];
+  const TilePlan t = plan_tile(p.H, p.W, K, cv, gridDim.x);
+  const int strips = t.W8 / SP, ncols = t.W8 + K - 1;
+  uint4* sw = smem;                                   // [K*K][cvb] weights of this sub-block (taps already flipped for dgrad)
+  uint4* sx = smem + K * K * t.cvb;
+  const int sub = blockIdx.x % t.nsub, idx = blockIdx.x / t.nsub;
+  if (idx >= t.per_sub) return;
+  const int cs = sub * t.cvb;                         // first chunk of the sub-block inside the group
+  for (int i = threadIdx.x; i < K * K * t.cvb; i += DW_THREADS) {
+    const int cb = i % t.cvb, tap = i / t.cvb;
+    const int r = tap / K, q = tap - r * K;
+    sw[i] = ld16(w + (size_t)((flip ? K - 1 - r : r) * K + (flip ? K - 1 - q : q)) * cg + (cs + cb) * 8);
+  }
+  const int tiles_h = (p.H + t.TH - 1) / t.TH, ntiles = p.N * tiles_h;
+  for (int tile = idx; tile < ntiles; tile += t.per_sub) {
+    const int n = tile / tiles_h, h0 = (tile - n * tiles_h) * t.TH;
+    __syncthreads();                                  // previous tile fully consumed (and the weights staged)
+    stage_rows(sx, t.xpitch, x, n, h0 - PAD, t.TH + K - 1, -PAD, ncols, p.H, p.W, p.C, c0 + cs * 8, t.cvb);
+    __syncthreads();
+    const int rows = min(t.TH, p.H - h0);
+    for (int it = threadIdx.x; it < rows * strips * t.cvb; it += DW_THREADS) {
+      const int cb = it % t.cvb;
+      const int r = (it / t.cvb) % rows, sidx = it / (t.cvb * rows);
+      float acc[SP][8];
 #pragma unroll
-    for (int o = 0; o < SP; ++o)
+      for (int o = 0; o < SP; ++o)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
-    for (int dh = 0; dh < K; ++dh) {
-      const int hh = hq + dh - PAD;
-      if (hh < 0 || hh >= p.H) continue;
-      float wt[K][8];
-      const int wr = flip ? (K - 1 - dh) : dh;
+        for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
+#pragma unroll 1
+      for (int dh = 0; dh < K; ++dh) {          // a real loop: unrolled, the compiler hoists all K*K weight chunks and spills
+        float wt[K][8];
 #pragma unroll
-      for (int dw = 0; dw < K; ++dw) unpack_bf8(ld16(w + (size_t)(wr * K + (flip ? (K - 1 - dw) : dw)) * cg + chunk * 8), wt[dw]);
-      const bf16_t* xrow = x + ((size_t)(n * p.H + hh) * p.W) * p.C + c;
+        for (int q = 0; q < K; ++q) unpack_bf8(sw[(dh * K + q) * t.cvb + cb], wt[q]);
+        const uint4* xr = sx + (r + dh) * t.xpitch + (sidx * SP) * t.cvb + cb;
 #pragma unroll
-      for (int ic = 0; ic < SP + K - 1; ++ic) {
-        const int ww = w0 - PAD + ic;
-        if (ww < 0 || ww >= p.W) continue;
-        float xv[8];
-        unpack_bf8(ld16(xrow + (size_t)ww * p.C), xv);
+        for (int ic = 0; ic < SP + K - 1; ++ic) {
+          float xv[8];
+          unpack_bf8(xr[ic * t.cvb], xv);
 #pragma unroll
-        for (int dw = 0; dw < K; ++dw) {
-          const int o = ic - dw;             // output pixel this (input column, tap) pair feeds
-          if (o >= 0 && o < SP) {
+          for (int q = 0; q < K; ++q) {
+            const int o = ic - q;                     // output pixel this (input column, tap) pair feeds
+            if (o >= 0 && o < SP) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[o][j] += xv[j] * wt[dw][j];
+              for (int j = 0; j < 8; ++j) acc[o][j] += xv[j] * wt[q][j];
+            }
           }
         }
       }
-    }
-    bf16_t* yrow = y + ((size_t)(n * p.H + hq) * p.W) * p.C + c;
+      bf16_t* yrow = y + ((size_t)(n * p.H + h0 + r) * p.W) * p.C + c0 + (cs + cb) * 8;
 #pragma unroll
-    for (int o = 0; o < SP; ++o) {
-      if (w0 + o < p.W) {
-        bf16_t* yo = yrow + (size_t)(w0 + o) * p.C;
-        if (accumulate) {
-          float old[8];
-          unpack_bf8(ld16(yo), old);
+      for (int o = 0; o < SP; ++o) {
+        const int wq = sidx * SP + o;
+        if (wq < p.W) {
+          bf16_t* yo = yrow + (size_t)wq * p.C;
+          if (accumulate) {
+            float old[8];
+            unpack_bf8(ld16(yo), old);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[o][j] += old[j];
+            for (int j = 0; j < 8; ++j) acc[o][j] += old[j];
+          }
+          *reinterpret_cast<uint4*>(yo) = pack_bf8(acc[o]);
         }
-        *reinterpret_cast<uint4*>(yo) = pack_bf8(acc[o]);
       }
     }
   }
@@ -90,63 +136,63 @@ __device__ __forceinline__ void dw_strip(const MixP& p, const bf16_t* __restrict
 __global__ __launch_bounds__(DW_THREADS) void dwconv_mix_kernel(MixP p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w0,
                                                                 const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
                                                                 const bf16_t* __restrict__ w3, bf16_t* __restrict__ y, int flip, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) uint4 dw_smem[];
   const int grp = blockIdx.y;
   const int c0 = p.split[grp], cg = p.split[grp + 1] - c0, cv = cg >> 3;
   if (cv == 0) return;
   const bf16_t* w = grp == 0 ? w0 : (grp == 1 ? w1 : (grp == 2 ? w2 : w3));
   switch (p.ksize[grp]) {   // blockIdx.y-uniform
-    case 1: dw_strip<1>(p, x, w, y, c0, cg, cv, flip, accumulate); break;
-    case 3: dw_strip<3>(p, x, w, y, c0, cg, cv, flip, accumulate); break;
-    case 5: dw_strip<5>(p, x, w, y, c0, cg, cv, flip, accumulate); break;
-    case 7: dw_strip<7>(p, x, w, y, c0, cg, cv, flip, accumulate); break;
-    default: dw_strip<9>(p, x, w, y, c0, cg, cv, flip, accumulate); break;
+    case 1: dw_tile<1>(p, x, w, y, c0, cg, cv, flip, accumulate, dw_smem); break;
+    case 3: dw_tile<3>(p, x, w, y, c0, cg, cv, flip, accumulate, dw_smem); break;
+    case 5: dw_tile<5>(p, x, w, y, c0, cg, cv, flip, accumulate, dw_smem); break;
+    case 7: dw_tile<7>(p, x, w, y, c0, cg, cv, flip, accumulate, dw_smem); break;
+    default: dw_tile<9>(p, x, w, y, c0, cg, cv, flip, accumulate, dw_smem); break;
   }
 }
 
-// wgrad body for one kernel size: per kernel row dh a lane accumulates the K taps of that row for 8 channels over its strips
-// (x row segment and dy strip loaded once per (strip, dh)), then the block reduces over lanes through LDS and issues one float atomic
-// per (tap, channel).
+// wgrad for one kernel size, ONE pass over the data: thread = (pixel lane, kernel row dh, chunk); per (row, strip) item it reads the dy
+// strip (shared by the K kernel-row threads: LDS broadcast) and the x row segment of its kernel row and accumulates the K taps of that
+// row for 8 channels in registers across all tiles of the workgroup; one LDS reduction over the pixel lanes at the very end, and the
+// workgroup's totals go to its slab slot with plain stores (a second kernel sums the slabs: deterministic, no atomics).
 template <int K>
-__device__ __forceinline__ void dw_wgrad_strip(const MixP& p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                               float* __restrict__ dw_out, int c0, int cg, int cv, int rows_per_block, float* red) {
+__device__ __forceinline__ void dw_wgrad_tile(const MixP& p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ slab0,
+                                              int c0, int cg, int cv, uint4* smem) {
   constexpr int PAD = K / 2;
-  const int npl = DW_THREADS / cv;
-  const int chunk = threadIdx.x % cv, pl = threadIdx.x / cv;
-  const bool active = pl < npl;
-  const int strips = (p.W + SP - 1) / SP;
-  const int nrows = p.N * p.H;
-  const int rbeg = blockIdx.x * rows_per_block, rend = min(nrows, rbeg + rows_per_block);
-  const int c = c0 + chunk * 8;
-  for (int dh = 0; dh < K; ++dh) {
-    float acc[K][8];
+  const TilePlan t = plan_tile(p.H, p.W, K, cv, gridDim.x);
+  const int strips = t.W8 / SP, ncols = t.W8 + K - 1;
+  uint4* sx = smem;
+  uint4* sdy = smem + (t.TH + K - 1) * t.xpitch;
+  const int dpitch = t.W8 * t.cvb;
+  const int sub = blockIdx.x % t.nsub, idx = blockIdx.x / t.nsub;
+  if (idx >= t.per_sub) return;
+  const int cs = sub * t.cvb;
+  const int L = DW_THREADS / (K * t.cvb);             // pixel lanes
+  const int cb = threadIdx.x % t.cvb, dh = (threadIdx.x / t.cvb) % K, li = threadIdx.x / (t.cvb * K);
+  float acc[K][8];
 #pragma unroll
-    for (int d = 0; d < K; ++d)
+  for (int d = 0; d < K; ++d)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[d][j] = 0.f;
-    if (active) {
-      for (int it = (rbeg * strips) + pl; it < rend * strips; it += npl) {
-        const int row = it / strips, sx = it - row * strips;
-        const int hq = row % p.H, n = row / p.H;
-        const int hh = hq + dh - PAD;
-        if (hh < 0 || hh >= p.H) continue;
-        const int w0 = sx * SP;
+    for (int j = 0; j < 8; ++j) acc[d][j] = 0.f;
+  const int tiles_h = (p.H + t.TH - 1) / t.TH, ntiles = p.N * tiles_h;
+  for (int tile = idx; tile < ntiles; tile += t.per_sub) {
+    const int n = tile / tiles_h, h0 = (tile - n * tiles_h) * t.TH;
+    __syncthreads();
+    stage_rows(sx, t.xpitch, x, n, h0 - PAD, t.TH + K - 1, -PAD, ncols, p.H, p.W, p.C, c0 + cs * 8, t.cvb);
+    stage_rows(sdy, dpitch, dy, n, h0, t.TH, 0, t.W8, p.H, p.W, p.C, c0 + cs * 8, t.cvb);
+    __syncthreads();
+    const int rows = min(t.TH, p.H - h0);
+    if (li < L) {
+      for (int it = li; it < rows * strips; it += L) {
+        const int r = it / strips, sidx = it - r * strips;
         float g[SP][8];
-        const bf16_t* grow = dy + ((size_t)row * p.W) * p.C + c;
+        const uint4* gr = sdy + r * dpitch + (sidx * SP) * t.cvb + cb;
 #pragma unroll
-        for (int o = 0; o < SP; ++o) {
-          if (w0 + o < p.W) unpack_bf8(ld16(grow + (size_t)(w0 + o) * p.C), g[o]);
-          else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) g[o][j] = 0.f;
-          }
-        }
-        const bf16_t* xrow = x + ((size_t)(n * p.H + hh) * p.W) * p.C + c;
+        for (int o = 0; o < SP; ++o) unpack_bf8(gr[o * t.cvb], g[o]);
+        const uint4* xr = sx + (r + dh) * t.xpitch + (sidx * SP) * t.cvb + cb;
 #pragma unroll
         for (int ic = 0; ic < SP + K - 1; ++ic) {
-          const int ww = w0 - PAD + ic;
-          if (ww < 0 || ww >= p.W) continue;
           float xv[8];
-          unpack_bf8(ld16(xrow + (size_t)ww * p.C), xv);
+          unpack_bf8(xr[ic * t.cvb], xv);
 #pragma unroll
           for (int d = 0; d < K; ++d) {
             const int o = ic - d;
@@ -158,37 +204,64 @@ __device__ __forceinline__ void dw_wgrad_strip(const MixP& p, const bf16_t* __re
         }
       }
     }
+  }
+  // totals over the pixel lanes: red[thread][8] per tap column d, summed by thread u = (dh, cb, j)
+  float* red = reinterpret_cast<float*>(smem);
+  float* slab = slab0 + (size_t)idx * K * K * cg;
 #pragma unroll
-    for (int d = 0; d < K; ++d) {
-      __syncthreads();
+  for (int d = 0; d < K; ++d) {
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[d][j];
-      __syncthreads();
-      for (int u = threadIdx.x; u < cg; u += DW_THREADS) {
-        float s = 0.f;
-        for (int q = 0; q < npl; ++q) s += red[(q * cv + (u >> 3)) * 8 + (u & 7)];
-        atomicAdd(dw_out + (size_t)(dh * K + d) * cg + u, s);
-      }
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = li < L ? acc[d][j] : 0.f;
+    __syncthreads();
+    for (int u = threadIdx.x; u < K * t.cvb * 8; u += DW_THREADS) {
+      const int j = u & 7, cbu = (u >> 3) % t.cvb, dhu = (u >> 3) / t.cvb;
+      float sum = 0.f;
+      for (int q = 0; q < L; ++q) sum += red[(((q * K) + dhu) * t.cvb + cbu) * 8 + j];
+      slab[(size_t)(dhu * K + d) * cg + (cs + cbu) * 8 + j] = sum;
     }
   }
 }
 
 __global__ __launch_bounds__(DW_THREADS) void dwconv_mix_wgrad_kernel(MixP p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                                      float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2,
-                                                                      float* __restrict__ d3, int rows_per_block) {
-  __shared__ float red[DW_THREADS * 8];
+                                                                      float* __restrict__ s0, float* __restrict__ s1, float* __restrict__ s2,
+                                                                      float* __restrict__ s3) {
+  extern __shared__ __attribute__((aligned(16))) uint4 dw_smem[];
   const int grp = blockIdx.y;
   const int c0 = p.split[grp], cg = p.split[grp + 1] - c0, cv = cg >> 3;
   if (cv == 0) return;
-  float* dw_out = grp == 0 ? d0 : (grp == 1 ? d1 : (grp == 2 ? d2 : d3));
+  float* slab = grp == 0 ? s0 : (grp == 1 ? s1 : (grp == 2 ? s2 : s3));
   switch (p.ksize[grp]) {
-    case 1: dw_wgrad_strip<1>(p, x, dy, dw_out, c0, cg, cv, rows_per_block, red); break;
-    case 3: dw_wgrad_strip<3>(p, x, dy, dw_out, c0, cg, cv, rows_per_block, red); break;
-    case 5: dw_wgrad_strip<5>(p, x, dy, dw_out, c0, cg, cv, rows_per_block, red); break;
-    case 7: dw_wgrad_strip<7>(p, x, dy, dw_out, c0, cg, cv, rows_per_block, red); break;
-    default: dw_wgrad_strip<9>(p, x, dy, dw_out, c0, cg, cv, rows_per_block, red); break;
+    case 1: dw_wgrad_tile<1>(p, x, dy, slab, c0, cg, cv, dw_smem); break;
+    case 3: dw_wgrad_tile<3>(p, x, dy, slab, c0, cg, cv, dw_smem); break;
+    case 5: dw_wgrad_tile<5>(p, x, dy, slab, c0, cg, cv, dw_smem); break;
+    case 7: dw_wgrad_tile<7>(p, x, dy, slab, c0, cg, cv, dw_smem); break;
+    default: dw_wgrad_tile<9>(p, x, dy, slab, c0, cg, cv, dw_smem); break;
   }
 }
+
+// dW_g[i] (+)= sum over the per_sub slabs of group g (blockIdx.y)
+struct SlabSet { const float* slab[4]; float* dw[4]; int n[4], count[4]; };
+__global__ __launch_bounds__(256) void dwconv_mix_wgrad_reduce_kernel(SlabSet s, int accumulate) {
+  const int g = blockIdx.y;
+  const float* src = g == 0 ? s.slab[0] : (g == 1 ? s.slab[1] : (g == 2 ? s.slab[2] : s.slab[3]));
+  float* dst = g == 0 ? s.dw[0] : (g == 1 ? s.dw[1] : (g == 2 ? s.dw[2] : s.dw[3]));
+  const int n = g == 0 ? s.n[0] : (g == 1 ? s.n[1] : (g == 2 ? s.n[2] : s.n[3]));
+  const int cnt = g == 0 ? s.count[0] : (g == 1 ? s.count[1] : (g == 2 ? s.count[2] : s.count[3]));
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // 8 loads in flight per lane: the loop is pure latency
+    int q = 0;
+    for (; q + 7 < cnt; q += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += src[(size_t)(q + u) * n + i];
+    }
+    for (; q < cnt; ++q) a[0] += src[(size_t)q * n + i];
+    dst[i] = (accumulate ? dst[i] : 0.f) + (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
+  }
+}
+
+constexpr int DW_BLOCKS = 256;   // workgroups per channel group (grid.x); every one loops over its share of the row tiles
+constexpr size_t DW_LDS = 4096 * 16 + 81 * 4 * 16;   // tile budget + the largest weight block (K = 9, cvb = 4)
 
 int check_mix(const yolo_mixconv_problem* p) {
   YOLO_CHECK_ARG(p != nullptr, "null problem");
@@ -212,19 +285,38 @@ MixP to_dev(const yolo_mixconv_problem* p) {
   return m;
 }
 
+// the tile budget is above the 64 KiB default limit of dynamic LDS
+int allow_big_lds() {
+  static int rc = -1;
+  if (rc < 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_mix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_mix_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_LDS);
+    if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    rc = 0;
+  }
+  return rc;
+}
+
 int launch_mix(const yolo_mixconv_problem* p, const void* x, const void* w0, const void* w1, const void* w2, const void* w3, void* y, int flip,
                int accumulate, void* stream) {
   int rc = check_mix(p);
   if (rc) return rc;
   YOLO_CHECK_ARG(x && y && w0 && w1 && w2 && w3, "null pointer");
-  const size_t items = (size_t)p->N * p->H * ((p->W + SP - 1) / SP) * (p->C / 16);      // strips x chunks of the largest group
-  size_t b = (items + DW_THREADS - 1) / DW_THREADS;
-  if (b > 1024) b = 1024;
-  if (b < 1) b = 1;
-  hipLaunchKernelGGL(dwconv_mix_kernel, dim3((unsigned)b, 4), dim3(DW_THREADS), 0, (hipStream_t)stream, to_dev(p), (const bf16_t*)x,
+  if ((rc = allow_big_lds())) return rc;
+  hipLaunchKernelGGL(dwconv_mix_kernel, dim3(DW_BLOCKS, 4), dim3(DW_THREADS), DW_LDS, (hipStream_t)stream, to_dev(p), (const bf16_t*)x,
                      (const bf16_t*)w0, (const bf16_t*)w1, (const bf16_t*)w2, (const bf16_t*)w3, (bf16_t*)y, flip, accumulate);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
+}
+
+// slab counts / sizes of the 4 groups for the two-phase weight gradient
+void wgrad_slabs(const yolo_mixconv_problem* p, int (&count)[4], int (&n)[4]) {
+  for (int g = 0; g < 4; ++g) {
+    const int cg = p->split[g + 1] - p->split[g], K = p->ksize[g];
+    n[g] = K * K * cg;
+    count[g] = cg ? plan_tile(p->H, p->W, K, cg / 8, DW_BLOCKS).per_sub : 0;
+  }
 }
 
 }  // namespace
@@ -239,17 +331,37 @@ extern "C" int yolo_dwconv_mix_dgrad(const yolo_mixconv_problem* p, const void* 
   return launch_mix(p, dy, w0, w1, w2, w3, dx, 1, accumulate, stream);
 }
 
+extern "C" size_t yolo_dwconv_mix_wgrad_workspace_bytes(const yolo_mixconv_problem* p) {
+  if (check_mix(p)) return 0;
+  int count[4], n[4];
+  wgrad_slabs(p, count, n);
+  size_t f = 0;
+  for (int g = 0; g < 4; ++g) f += (size_t)count[g] * n[g];
+  return f * sizeof(float);
+}
+
 extern "C" int yolo_dwconv_mix_wgrad(const yolo_mixconv_problem* p, const void* x, const void* dy, float* dw0, float* dw1, float* dw2,
-                                     float* dw3, void* stream) {
+                                     float* dw3, void* workspace, size_t workspace_bytes, int accumulate, void* stream) {
   int rc = check_mix(p);
   if (rc) return rc;
-  YOLO_CHECK_ARG(x && dy && dw0 && dw1 && dw2 && dw3, "null pointer");
-  const int nrows = p->N * p->H;
-  int blocks = nrows < 256 ? nrows : 256;
-  if (blocks < 1) blocks = 1;
-  const int ppb = (nrows + blocks - 1) / blocks;      // image rows per workgroup
-  hipLaunchKernelGGL(dwconv_mix_wgrad_kernel, dim3(blocks, 4), dim3(DW_THREADS), 0, (hipStream_t)stream, to_dev(p), (const bf16_t*)x,
-                     (const bf16_t*)dy, dw0, dw1, dw2, dw3, ppb);
+  YOLO_CHECK_ARG(x && dy && dw0 && dw1 && dw2 && dw3 && workspace, "null pointer");
+  YOLO_CHECK_ARG(workspace_bytes >= yolo_dwconv_mix_wgrad_workspace_bytes(p), "workspace too small (yolo_dwconv_mix_wgrad_workspace_bytes)");
+  if ((rc = allow_big_lds())) return rc;
+  SlabSet s;
+  wgrad_slabs(p, s.count, s.n);
+  float* ws = (float*)workspace;
+  float* dws[4] = {dw0, dw1, dw2, dw3};
+  int nmax = 1;
+  for (int g = 0; g < 4; ++g) {
+    s.slab[g] = ws;
+    s.dw[g] = dws[g];
+    ws += (size_t)s.count[g] * s.n[g];
+    if (s.n[g] > nmax) nmax = s.n[g];
+  }
+  hipLaunchKernelGGL(dwconv_mix_wgrad_kernel, dim3(DW_BLOCKS, 4), dim3(DW_THREADS), DW_LDS, (hipStream_t)stream, to_dev(p), (const bf16_t*)x,
+                     (const bf16_t*)dy, (float*)s.slab[0], (float*)s.slab[1], (float*)s.slab[2], (float*)s.slab[3]);
+  YOLO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dwconv_mix_wgrad_reduce_kernel, dim3((nmax + 255) / 256, 4), dim3(256), 0, (hipStream_t)stream, s, accumulate);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

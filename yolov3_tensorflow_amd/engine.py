@@ -361,7 +361,8 @@ class Graph(object):
                 n_dg += _round_up(op.y.wp.numel, SLOT)
         self.w_dgrad = torch.zeros(max(n_dg, SLOT), dtype=torch.bfloat16, device=dev)
         # one slab workspace for the two-phase weight gradients (they run back to back on one stream)
-        ws_bytes = max([ops.conv2d_wgrad_workspace_bytes(op.y.p) for op in self.tape if isinstance(op, ConvOp)] + [16])
+        ws_bytes = max([ops.conv2d_wgrad_workspace_bytes(op.y.p) for op in self.tape if isinstance(op, ConvOp)] +
+                       [ops.dwconv_mix_wgrad_workspace_bytes(op.y.mp) for op in self.tape if isinstance(op, MixConvOp)] + [16])
         self.wgrad_ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
         # workspace + hand-off words of the single-launch BatchNorm backward (all on the main stream, one at a time)
         cmax = max([op.out.shape[3] for op in self.tape if isinstance(op, ApplyOp)] + [8])
@@ -561,7 +562,7 @@ class MixConvOp(object):
 
     def backward(self):
         y = self.y
-        self.g.on_wgrad_stream(lambda: ops.dwconv_mix_wgrad(y.mp, y.x.buf, y.dy, self.dw))
+        self.g.on_wgrad_stream(lambda: ops.dwconv_mix_wgrad(y.mp, y.x.buf, y.dy, self.dw, self.g.wgrad_ws))
         ops.dwconv_mix_dgrad(y.mp, y.dy, self.w, y.x.grad, accumulate=self.acc)
 
 

@@ -191,8 +191,13 @@ def dwconv_mix_dgrad(p, dy, w, dx, accumulate=False):
           'yolo_dwconv_mix_dgrad')
 
 
-def dwconv_mix_wgrad(p, x, dy, dw):
-    check(_lib.load().yolo_dwconv_mix_wgrad(C.byref(p), _p(x), _p(dy), _p(dw[0]), _p(dw[1]), _p(dw[2]), _p(dw[3]), _stream()),
+def dwconv_mix_wgrad_workspace_bytes(p):
+    return int(_lib.load().yolo_dwconv_mix_wgrad_workspace_bytes(C.byref(p)))
+
+
+def dwconv_mix_wgrad(p, x, dy, dw, workspace, accumulate=False):
+    check(_lib.load().yolo_dwconv_mix_wgrad(C.byref(p), _p(x), _p(dy), _p(dw[0]), _p(dw[1]), _p(dw[2]), _p(dw[3]), _p(workspace),
+                                            workspace.numel() * workspace.element_size(), int(accumulate), _stream()),
           'yolo_dwconv_mix_wgrad')
 
 
