@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of the conv kernels on the ResNet18-YOLOv3 layer shapes (batch 32, 416x416).  Usage:
-    python tools/conv_bench.py [--layers 64,128,256,512,stem] [--passes fwd,dgrad,wgrad] [--iters 30]"""
+    python tools/conv_bench.py [--layers 64,128,256,512,stem] [--passes fwd,dgrad,wgrad,wgrad2]  (wgrad = one-pass atomics, wgrad2 = two-phase slabs + reduce, the training path) [--iters 30]"""
 import argparse
 import os
 import sys
@@ -51,11 +51,13 @@ def main():
         dx = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
         dw = torch.zeros((160 if os.environ.get('YOLO_WGRAD_EPI') == '3' else 1) * Cout, k, k, Cin, device=dev)
         rows = ops.conv2d_stat_rows(p)
+        wsp = torch.empty(max(ops.conv2d_wgrad_workspace_bytes(p), 16) // 4, device=dev)
         ss, sq = torch.zeros(rows, Cout, device=dev), torch.zeros(rows, Cout, device=dev)
         flops = 2.0 * N * p.Ho * p.Wo * Cout * Cin * k * k
         fns = {'fwd': lambda: ops.conv2d_fwd(p, x, w, y, stat_sum=ss, stat_sq=sq),
                'dgrad': lambda: ops.conv2d_dgrad(p, dy, wd, dx),
-               'wgrad': lambda: ops.conv2d_wgrad(p, x, dy, dw)}
+               'wgrad': lambda: ops.conv2d_wgrad(p, x, dy, dw),
+               'wgrad2': lambda: ops.conv2d_wgrad_reduce(p, x, dy, dw, wsp)}
         for ps in a.passes.split(','):
             if ps == 'dgrad' and Cin % 64:
                 continue
