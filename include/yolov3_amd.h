@@ -93,6 +93,16 @@ int yolo_bn_stats(const void* x, int M, int C, float* partial, void* stream);
 int yolo_bn_finalize(const float* psum, const float* psq, int P, int64_t row_stride, int C, float count, const float* gamma,
                      const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* scale,
                      float* shift, float* mean, float* rstd, void* stream);
+/* The same finalize for up to 4 BatchNorms over consecutive channel groups of ONE tensor (MixNet's grouped BN: shared statistics work
+ * vectors, separate gamma / beta / moving statistics / gradient slots): split[0..ngroups] (host) = group boundaries, the pointer arrays
+ * (host arrays of device pointers) have ngroups entries.  One launch instead of one per group. */
+int yolo_bn_finalize_grouped(const float* psum, const float* psq, int P, int64_t row_stride, int C, float count, int ngroups,
+                             const int32_t* split, const float* const* gamma, const float* const* beta, float eps, float momentum,
+                             float* const* moving_mean, float* const* moving_var, float* scale, float* shift, float* mean, float* rstd,
+                             void* stream);
+int yolo_bn_bwd_finalize_grouped(const float* partial, int P, int64_t row_stride, int64_t q_stride, int C, int which, float count,
+                                 int ngroups, const int32_t* split, float* const* dgamma, float* const* dbeta, float* k1, float* k2,
+                                 void* stream);
 /* out = act(y*scale + shift + T); T = 0 (res NULL), res (res_scale NULL) or res*res_scale + res_shift; scale NULL = identity */
 int yolo_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
                     const float* res_shift, void* out, int64_t M, int C, int relu, void* stream);

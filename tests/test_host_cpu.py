@@ -113,7 +113,7 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
     c = collections.Counter(mocked_kernels)
     assert c['conv2d_fwd'] == n_conv and c['conv2d_wgrad_reduce'] == n_conv and c['conv2d_dgrad'] == n_conv - 1
     assert c['loss_fwd_bwd'] == 1 and c['radam_l2_step'] == 1 and c['radam_schedule'] == 1 and c['upcat_split_bwd'] == 2
-    assert c['bn_finalize'] == n_bn
+    assert c['bn_finalize'] + 4 * c['bn_finalize_grouped'] == n_bn      # MixNet: one grouped launch per 4 group BatchNorms
     if n_dw:
         assert c['dwconv_mix_fwd'] == 8 and c['dwconv_mix_dgrad'] == 8 and c['dwconv_mix_wgrad'] == 8
 

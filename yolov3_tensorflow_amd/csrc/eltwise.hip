@@ -128,6 +128,72 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   }
 }
 
+// Grouped variants (MixNet's 4 BatchNorms over the channel groups of one tensor share statistics work vectors but own separate gamma /
+// beta / moving-statistics / gradient slots): one launch instead of one per group.  Pointers are picked by comparisons (no indexing of
+// the by-value table with a runtime index: that would put it in scratch).
+struct BnGroups {
+  int n, split[5];
+  const float* gamma[4]; const float* beta[4];
+  float* mm[4]; float* mv[4];
+  float* dgamma[4]; float* dbeta[4];
+};
+__device__ __forceinline__ int bn_group_of(const BnGroups& g, int c, int& local) {
+  int s = 0;
+  if (g.n > 1 && c >= g.split[1]) s = 1;
+  if (g.n > 2 && c >= g.split[2]) s = 2;
+  if (g.n > 3 && c >= g.split[3]) s = 3;
+  local = c - (s == 0 ? g.split[0] : (s == 1 ? g.split[1] : (s == 2 ? g.split[2] : g.split[3])));
+  return s;
+}
+#define BN_PICK(arr, s) ((s) == 0 ? (arr)[0] : ((s) == 1 ? (arr)[1] : ((s) == 2 ? (arr)[2] : (arr)[3])))
+
+__global__ __launch_bounds__(1024) void bn_finalize_grouped_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int P,
+                                                                   size_t rstride, int C, float count, BnGroups grp, float eps, float momentum,
+                                                                   float* __restrict__ scale, float* __restrict__ shift,
+                                                                   float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  const float* const src[2] = {psum, psq};
+  double tot[2];
+  if (!column_reduce<2>(src, P, rstride, C, tot)) return;
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  int l;
+  const int sg = bn_group_of(grp, c, l);
+  const double mean = tot[0] / (double)count;
+  double var = tot[1] / (double)count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = BN_PICK(grp.gamma, sg)[l], b = BN_PICK(grp.beta, sg)[l];
+  const float sc = g * rstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  mean_o[c] = (float)mean;
+  rstd_o[c] = rstd;
+  float* mm = BN_PICK(grp.mm, sg);
+  float* mv = BN_PICK(grp.mv, sg);
+  if (mm) {
+    const double unb = count > 1.f ? var * ((double)count / ((double)count - 1.0)) : var;
+    mm[l] = momentum * mm[l] + (1.f - momentum) * (float)mean;
+    mv[l] = momentum * mv[l] + (1.f - momentum) * (float)unb;
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_grouped_kernel(const float* __restrict__ partial, int P, size_t rstride, size_t qstride,
+                                                                       int C, int which, float count, BnGroups grp, float* __restrict__ k1,
+                                                                       float* __restrict__ k2) {
+  const float* const src[2] = {partial, partial + (size_t)which * qstride};
+  double tot[2];
+  if (!column_reduce<2>(src, P, rstride, C, tot)) return;
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  int l;
+  const int sg = bn_group_of(grp, c, l);
+  float* dg = BN_PICK(grp.dgamma, sg);
+  float* db = BN_PICK(grp.dbeta, sg);
+  if (dg) dg[l] = (float)tot[1];
+  if (db) db[l] = (float)tot[0];
+  k1[c] = (float)(tot[0] / (double)count);
+  k2[c] = (float)(tot[1] / (double)count);
+}
+#undef BN_PICK
+
 // ---- out = act(y * scale + shift + T),  T in {0, res, y2 * scale2 + shift2};  scale == nullptr means identity ----
 __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const bf16_t* __restrict__ res,
@@ -833,6 +899,56 @@ extern "C" int yolo_bn_finalize(const float* psum, const float* psq, int P, int6
   YOLO_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "moving_mean and moving_var go together");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, psum, psq, P, (size_t)row_stride, C, count,
                      gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+namespace {
+int fill_groups(BnGroups* g, int ngroups, const int32_t* split, int C) {
+  YOLO_CHECK_ARG(ngroups >= 1 && ngroups <= 4 && split, "1..4 groups");
+  g->n = ngroups;
+  for (int i = 0; i < 5; ++i) g->split[i] = i <= ngroups ? split[i] : C;
+  YOLO_CHECK_ARG(split[0] == 0 && split[ngroups] == C, "split must cover [0, C)");
+  for (int i = 0; i < ngroups; ++i) YOLO_CHECK_ARG(split[i + 1] > split[i], "empty group (drop it from the table)");
+  for (int i = 0; i < 4; ++i) { g->gamma[i] = g->beta[i] = nullptr; g->mm[i] = g->mv[i] = g->dgamma[i] = g->dbeta[i] = nullptr; }
+  return YOLO_OK;
+}
+}  // namespace
+
+extern "C" int yolo_bn_finalize_grouped(const float* psum, const float* psq, int P, int64_t row_stride, int C, float count, int ngroups,
+                                        const int32_t* split, const float* const* gamma, const float* const* beta, float eps, float momentum,
+                                        float* const* moving_mean, float* const* moving_var, float* scale, float* shift, float* mean,
+                                        float* rstd, void* stream) {
+  YOLO_CHECK_ARG(psum && psq && scale && shift && mean && rstd && gamma && beta && P > 0 && C > 0 && count > 0.f, "bad argument");
+  YOLO_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "moving_mean and moving_var go together");
+  BnGroups g;
+  int rc = fill_groups(&g, ngroups, split, C);
+  if (rc) return rc;
+  for (int i = 0; i < ngroups; ++i) {
+    YOLO_CHECK_ARG(gamma[i] && beta[i], "null gamma / beta");
+    g.gamma[i] = gamma[i]; g.beta[i] = beta[i];
+    if (moving_mean) { g.mm[i] = moving_mean[i]; g.mv[i] = moving_var[i]; }
+  }
+  hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, psum, psq, P, (size_t)row_stride, C,
+                     count, g, eps, momentum, scale, shift, mean, rstd);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_bwd_finalize_grouped(const float* partial, int P, int64_t row_stride, int64_t q_stride, int C, int which, float count,
+                                            int ngroups, const int32_t* split, float* const* dgamma, float* const* dbeta, float* k1,
+                                            float* k2, void* stream) {
+  YOLO_CHECK_ARG(partial && k1 && k2 && P > 0 && C > 0 && (which == 1 || which == 2) && count > 0.f, "bad argument");
+  YOLO_CHECK_ARG(q_stride >= C && row_stride >= 3 * q_stride, "bad strides");
+  BnGroups g;
+  int rc = fill_groups(&g, ngroups, split, C);
+  if (rc) return rc;
+  for (int i = 0; i < ngroups; ++i) {
+    if (dgamma) g.dgamma[i] = dgamma[i];
+    if (dbeta) g.dbeta[i] = dbeta[i];
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_grouped_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,
+                     (size_t)q_stride, C, which, count, g, k1, k2);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

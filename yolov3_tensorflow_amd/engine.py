@@ -141,8 +141,23 @@ class MultiBN(object):
         for bn, c0 in self.parts:
             bn.allocate(dev, ps, work, c0)
 
-    fwd_finalize = BNState.fwd_finalize
-    bwd_finalize = BNState.bwd_finalize
+    def _bounds(self):
+        return [c0 for _, c0 in self.parts] + [self.parts[-1][1] + self.parts[-1][0].C]
+
+    def fwd_finalize(self, psum, psq, P, row_stride, count, training):
+        if not training or self.parts[0][1] != 0 or self._bounds()[-1] != self.C:
+            return BNState.fwd_finalize(self, psum, psq, P, row_stride, count, training)
+        bns = [bn for bn, _ in self.parts]                                         # one launch for the (up to 4) groups
+        ops.bn_finalize_grouped(psum, psq, P, row_stride, self.C, count, self._bounds(), [b.v_gamma for b in bns], [b.v_beta for b in bns],
+                                BN_EPSILON, BN_MOMENTUM, [b.moving_mean for b in bns], [b.moving_var for b in bns], self.scale, self.shift,
+                                self.mean, self.rstd)
+
+    def bwd_finalize(self, partial, P, Cfull, which, count):
+        if self.parts[0][1] != 0 or self._bounds()[-1] != self.C:
+            return BNState.bwd_finalize(self, partial, P, Cfull, which, count)
+        bns = [bn for bn, _ in self.parts]
+        ops.bn_bwd_finalize_grouped(partial, P, self.C, which, count, self._bounds(), [b.v_dgamma for b in bns], [b.v_dbeta for b in bns],
+                                    self.k1, self.k2, row_stride=3 * Cfull, q_stride=Cfull)
 
 
 class Val(object):

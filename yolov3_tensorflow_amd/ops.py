@@ -102,6 +102,31 @@ def bn_finalize(psum, psq, P, row_stride, Cc, count, gamma, beta, eps, momentum,
           'yolo_bn_finalize')
 
 
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def bn_finalize_grouped(psum, psq, P, row_stride, Cc, count, split, gammas, betas, eps, momentum, moving_means, moving_vars, scale, shift,
+                        mean, rstd):
+    """one launch for the BatchNorms of consecutive channel groups (split = boundaries, len(gammas) groups)"""
+    n = len(gammas)
+    sp = (C.c_int32 * (n + 1))(*split)
+    mm = None if moving_means is None else _ptr_array(moving_means)
+    mv = None if moving_vars is None else _ptr_array(moving_vars)
+    check(_lib.load().yolo_bn_finalize_grouped(_p(psum), _p(psq), P, row_stride, Cc, float(count), n, sp, _ptr_array(gammas),
+                                               _ptr_array(betas), eps, momentum, mm, mv, _p(scale), _p(shift), _p(mean), _p(rstd),
+                                               _stream()), 'yolo_bn_finalize_grouped')
+
+
+def bn_bwd_finalize_grouped(partial, P, Cc, which, count, split, dgammas, dbetas, k1, k2, row_stride=None, q_stride=None):
+    n = len(dgammas)
+    sp = (C.c_int32 * (n + 1))(*split)
+    q = Cc if q_stride is None else q_stride
+    rs = 3 * q if row_stride is None else row_stride
+    check(_lib.load().yolo_bn_bwd_finalize_grouped(_p(partial), P, rs, q, Cc, which, float(count), n, sp, _ptr_array(dgammas),
+                                                   _ptr_array(dbetas), _p(k1), _p(k2), _stream()), 'yolo_bn_bwd_finalize_grouped')
+
+
 def bn_act_fwd(y, scale, shift, out, M, Cc, relu, res=None, res_scale=None, res_shift=None):
     check(_lib.load().yolo_bn_act_fwd(_p(y), _p(scale), _p(shift), _p(res), _p(res_scale), _p(res_shift), _p(out), M, Cc, int(relu),
                                       _stream()), 'yolo_bn_act_fwd')
