@@ -133,6 +133,12 @@ int yolo_bn_act_bwd_fused(const void* dout, const void* out, int relu, int64_t M
                           const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dy, int acc_dy, const void* y2,
                           const float* a2, const float* mean2, const float* rstd2, float* dgamma2, float* dbeta2, void* dy2,
                           void* dres, int acc_dres, float* workspace, int* sync_words, void* stream);
+/* the same with a grouped BatchNorm as the main branch (dgamma / dbeta: host arrays of ngroups device pointers, split as above) */
+int yolo_bn_act_bwd_fused_grouped(const void* dout, const void* out, int relu, int64_t M, int C, const void* y, const float* a1,
+                                  const float* mean, const float* rstd, int ngroups, const int32_t* split, float* const* dgamma,
+                                  float* const* dbeta, void* dy, int acc_dy, const void* y2, const float* a2, const float* mean2,
+                                  const float* rstd2, float* dgamma2, float* dbeta2, void* dy2, void* dres, int acc_dres,
+                                  float* workspace, int* sync_words, void* stream);
 int yolo_bn_fused_timeouts(const int* sync_words, int* host_out);
 /* the same two passes through the stem's max-pool (rows = pre-pool pixels N*H*W) */
 /* (with relu and non-NULL gamma/beta the sums are taken over the pooled map: xhat = (out - beta) / gamma, y/argmax are not read) */

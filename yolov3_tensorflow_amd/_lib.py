@@ -61,6 +61,7 @@ SIGNATURES = {
     'yolo_bn_bwd_fused_workspace_floats': (C.c_int64, [I]),
     'yolo_bn_bwd_fused_sync_words': (I, []),
     'yolo_bn_act_bwd_fused': (I, [P, P, I, C.c_int64, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P, P, P]),
+    'yolo_bn_act_bwd_fused_grouped': (I, [P, P, I, C.c_int64, I, P, P, P, P, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P, P, P]),
     'yolo_bn_fused_timeouts': (I, [P, P]),
     'yolo_bn_pool_bwd_reduce': (I, [P, P, P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, P]),
     'yolo_bn_pool_bwd_apply': (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),

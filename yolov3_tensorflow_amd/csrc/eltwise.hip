@@ -192,7 +192,6 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_grouped_kernel(const flo
   k1[c] = (float)(tot[0] / (double)count);
   k2[c] = (float)(tot[1] / (double)count);
 }
-#undef BN_PICK
 
 // ---- out = act(y * scale + shift + T),  T in {0, res, y2 * scale2 + shift2};  scale == nullptr means identity ----
 __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
@@ -614,7 +613,7 @@ __device__ __forceinline__ void grid_arrive_wait(int* sync) {
 
 struct FusedBwdArgs {
   const bf16_t* dout; const bf16_t* out; int relu;
-  const bf16_t* y; const float* a1; const float* mean; const float* rstd; float* dgamma; float* dbeta; bf16_t* dy; int acc_dy;
+  const bf16_t* y; const float* a1; const float* mean; const float* rstd; BnGroups grp; bf16_t* dy; int acc_dy;   // grp: dgamma / dbeta slots
   const bf16_t* y2; const float* a2; const float* mean2; const float* rstd2; float* dgamma2; float* dbeta2; bf16_t* dy2;
   bf16_t* dres; int acc_dres;
   size_t total;       // M * C / 8 chunks
@@ -717,8 +716,12 @@ __global__ __launch_bounds__(FB_THREADS) void bn_bwd_fused_kernel(FusedBwdArgs a
         const float tot = (float)((dred[slot * 4] + dred[slot * 4 + 1]) + (dred[slot * 4 + 2] + dred[slot * 4 + 3]));
         const int q = col / C, c = col - q * C;
         st_agent(a.kbuf + col, tot);
-        if (q == 0) { if (a.dbeta) a.dbeta[c] = tot; if (HAS2 && a.dbeta2) a.dbeta2[c] = tot; }
-        if (q == 1 && a.dgamma) a.dgamma[c] = tot;
+        int l;
+        const int sg = bn_group_of(a.grp, c, l);
+        float* const db = BN_PICK(a.grp.dbeta, sg);
+        float* const dg = BN_PICK(a.grp.dgamma, sg);
+        if (q == 0) { if (db) db[l] = tot; if (HAS2 && a.dbeta2) a.dbeta2[c] = tot; }
+        if (q == 1 && dg) dg[l] = tot;
         if (HAS2 && q == 2 && a.dgamma2) a.dgamma2[c] = tot;
       }
     }
@@ -1030,10 +1033,11 @@ extern "C" int yolo_bn_fused_timeouts(const int* sync_words, int* host_out) {
   return YOLO_OK;
 }
 
-extern "C" int yolo_bn_act_bwd_fused(const void* dout, const void* out, int relu, int64_t M, int C, const void* y, const float* a1,
-                                     const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dy, int acc_dy,
-                                     const void* y2, const float* a2, const float* mean2, const float* rstd2, float* dgamma2,
-                                     float* dbeta2, void* dy2, void* dres, int acc_dres, float* workspace, int* sync_words, void* stream) {
+namespace {
+int launch_bn_bwd_fused(const void* dout, const void* out, int relu, int64_t M, int C, const void* y, const float* a1, const float* mean,
+                        const float* rstd, const BnGroups& grp, void* dy, int acc_dy, const void* y2, const float* a2, const float* mean2,
+                        const float* rstd2, float* dgamma2, float* dbeta2, void* dy2, void* dres, int acc_dres, float* workspace,
+                        int* sync_words, void* stream) {
   YOLO_CHECK_ARG(dout && y && a1 && mean && rstd && dy && workspace && sync_words && M > 0 && chan_ok(C), "bad argument");
   YOLO_CHECK_ARG(!relu || out, "relu needs out");
   YOLO_CHECK_ARG(!y2 || (a2 && mean2 && rstd2 && dy2), "second BN branch incomplete");
@@ -1045,7 +1049,7 @@ extern "C" int yolo_bn_act_bwd_fused(const void* dout, const void* out, int relu
   if (need > 11 || (y2 && need > 6) || need < (size_t)g_fused_min_chunks) return 1;
   FusedBwdArgs a;
   a.dout = (const bf16_t*)dout; a.out = (const bf16_t*)out; a.relu = relu;
-  a.y = (const bf16_t*)y; a.a1 = a1; a.mean = mean; a.rstd = rstd; a.dgamma = dgamma; a.dbeta = dbeta; a.dy = (bf16_t*)dy; a.acc_dy = acc_dy;
+  a.y = (const bf16_t*)y; a.a1 = a1; a.mean = mean; a.rstd = rstd; a.grp = grp; a.dy = (bf16_t*)dy; a.acc_dy = acc_dy;
   a.y2 = (const bf16_t*)y2; a.a2 = a2; a.mean2 = mean2; a.rstd2 = rstd2; a.dgamma2 = dgamma2; a.dbeta2 = dbeta2; a.dy2 = (bf16_t*)dy2;
   a.dres = (bf16_t*)dres; a.acc_dres = acc_dres;
   a.total = total; a.C = C; a.count = (float)M;
@@ -1057,6 +1061,37 @@ extern "C" int yolo_bn_act_bwd_fused(const void* dout, const void* out, int relu
 #undef YOLO_FB
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
+}
+}  // namespace
+
+extern "C" int yolo_bn_act_bwd_fused(const void* dout, const void* out, int relu, int64_t M, int C, const void* y, const float* a1,
+                                     const float* mean, const float* rstd, float* dgamma, float* dbeta, void* dy, int acc_dy,
+                                     const void* y2, const float* a2, const float* mean2, const float* rstd2, float* dgamma2,
+                                     float* dbeta2, void* dy2, void* dres, int acc_dres, float* workspace, int* sync_words, void* stream) {
+  BnGroups g;
+  const int32_t split[2] = {0, C};
+  int rc = fill_groups(&g, 1, split, C);
+  if (rc) return rc;
+  g.dgamma[0] = dgamma; g.dbeta[0] = dbeta;
+  return launch_bn_bwd_fused(dout, out, relu, M, C, y, a1, mean, rstd, g, dy, acc_dy, y2, a2, mean2, rstd2, dgamma2, dbeta2, dy2, dres, acc_dres,
+                             workspace, sync_words, stream);
+}
+
+// the main branch is a grouped BatchNorm (see yolo_bn_finalize_grouped): dgamma / dbeta are host arrays of ngroups device pointers
+extern "C" int yolo_bn_act_bwd_fused_grouped(const void* dout, const void* out, int relu, int64_t M, int C, const void* y, const float* a1,
+                                             const float* mean, const float* rstd, int ngroups, const int32_t* split, float* const* dgamma,
+                                             float* const* dbeta, void* dy, int acc_dy, const void* y2, const float* a2, const float* mean2,
+                                             const float* rstd2, float* dgamma2, float* dbeta2, void* dy2, void* dres, int acc_dres,
+                                             float* workspace, int* sync_words, void* stream) {
+  BnGroups g;
+  int rc = fill_groups(&g, ngroups, split, C);
+  if (rc) return rc;
+  for (int i = 0; i < ngroups; ++i) {
+    if (dgamma) g.dgamma[i] = dgamma[i];
+    if (dbeta) g.dbeta[i] = dbeta[i];
+  }
+  return launch_bn_bwd_fused(dout, out, relu, M, C, y, a1, mean, rstd, g, dy, acc_dy, y2, a2, mean2, rstd2, dgamma2, dbeta2, dy2, dres, acc_dres,
+                             workspace, sync_words, stream);
 }
 
 static int pool_grad(PoolGrad* g, const void* dout, const void* out, const uint8_t* argmax, int relu, int N, int H, int W, int C, int Ho,

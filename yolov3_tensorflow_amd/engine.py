@@ -650,15 +650,22 @@ class ApplyOp(object):
     def backward(self):
         out, m, o = self.out, self.m_src, self.o_src
         mb, ob = self.m_bn, self.o_bn
-        if self.g.fused_bn_bwd and mb is not None and len(mb.parts) == 1 and (ob is None or len(ob.parts) == 1):
+        grouped = mb is not None and len(mb.parts) > 1
+        if self.g.fused_bn_bwd and mb is not None and (ob is None or len(ob.parts) == 1) and \
+                (not grouped or (mb.parts[0][1] == 0 and mb._bounds()[-1] == mb.C)):
             kw = {}
             if o is not None:
                 if ob is not None:
                     kw.update(y2=o.buf, a2=ob.scale, mean2=ob.mean, rstd2=ob.rstd, dgamma2=ob.v_dgamma, dbeta2=ob.v_dbeta, dy2=o.dy)
                 else:
                     kw.update(dres=o.grad, acc_dres=self.o_acc)
-            if ops.bn_act_bwd_fused(out.grad, out.buf, self.relu, self.M, self.C, m.buf, mb.scale, mb.mean, mb.rstd, mb.v_dgamma,
-                                    mb.v_dbeta, m.dy if self.m_dst == 'dy' else m.grad, self.g.bn_ws, self.g.bn_sync,
+            if grouped:
+                dgs = (mb._bounds(), [b.v_dgamma for b, _ in mb.parts])
+                dbs = [b.v_dbeta for b, _ in mb.parts]
+            else:
+                dgs, dbs = mb.v_dgamma, mb.v_dbeta
+            if ops.bn_act_bwd_fused(out.grad, out.buf, self.relu, self.M, self.C, m.buf, mb.scale, mb.mean, mb.rstd, dgs,
+                                    dbs, m.dy if self.m_dst == 'dy' else m.grad, self.g.bn_ws, self.g.bn_sync,
                                     acc_dy=self.m_acc, **kw):
                 return
         if mb is not None or ob is not None:

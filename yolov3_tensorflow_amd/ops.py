@@ -168,9 +168,17 @@ def bn_bwd_fused_sync_words():
 def bn_act_bwd_fused(dout, out, relu, M, Cc, y, a1, mean, rstd, dgamma, dbeta, dy, workspace, sync, acc_dy=False, y2=None, a2=None,
                      mean2=None, rstd2=None, dgamma2=None, dbeta2=None, dy2=None, dres=None, acc_dres=False):
     """single-launch BN(+ReLU, + residual / second BN) backward; returns False (nothing launched) if the tensor is too large for it"""
-    rc = _lib.load().yolo_bn_act_bwd_fused(_p(dout), _p(out), int(relu), M, Cc, _p(y), _p(a1), _p(mean), _p(rstd), _p(dgamma), _p(dbeta),
-                                           _p(dy), int(acc_dy), _p(y2), _p(a2), _p(mean2), _p(rstd2), _p(dgamma2), _p(dbeta2), _p(dy2),
-                                           _p(dres), int(acc_dres), _p(workspace), _p(sync), _stream())
+    if isinstance(dgamma, (list, tuple)):          # grouped main BatchNorm: (split, [dgamma...], [dbeta...])
+        split, dgs = dgamma
+        sp = (C.c_int32 * len(split))(*split)
+        rc = _lib.load().yolo_bn_act_bwd_fused_grouped(_p(dout), _p(out), int(relu), M, Cc, _p(y), _p(a1), _p(mean), _p(rstd), len(dgs), sp,
+                                                       _ptr_array(dgs), _ptr_array(dbeta), _p(dy), int(acc_dy), _p(y2), _p(a2), _p(mean2),
+                                                       _p(rstd2), _p(dgamma2), _p(dbeta2), _p(dy2), _p(dres), int(acc_dres), _p(workspace),
+                                                       _p(sync), _stream())
+    else:
+        rc = _lib.load().yolo_bn_act_bwd_fused(_p(dout), _p(out), int(relu), M, Cc, _p(y), _p(a1), _p(mean), _p(rstd), _p(dgamma), _p(dbeta),
+                                               _p(dy), int(acc_dy), _p(y2), _p(a2), _p(mean2), _p(rstd2), _p(dgamma2), _p(dbeta2), _p(dy2),
+                                               _p(dres), int(acc_dres), _p(workspace), _p(sync), _stream())
     if rc == 1:
         return False
     check(rc, 'yolo_bn_act_bwd_fused')
