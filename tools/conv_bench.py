@@ -36,9 +36,6 @@ def main():
     for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):      # e.g. YOLO_TUNE=s2_classes=0,wgrad_strip=0
         k, v = kv.split('=')
         ops.set_tuning(k, int(v))
-    if os.environ.get('YOLO_STRIP'):
-        ops.set_tuning('strip_bm', int(os.environ['YOLO_STRIP']))
-        ops.set_tuning('strip_bn', int(os.environ.get('YOLO_STRIP_BN', '0')))
     for name in a.layers.split(','):
         H, W, Cin, Cout, k, s, pad = LAYERS[name]
         p = ops.conv_problem(N, H, W, Cin, Cout, k, s, pad)
