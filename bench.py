@@ -47,7 +47,7 @@ def synthetic_batch(N, H, W, class_num, rank, T=8):
     return images, torch.from_numpy(labels.reshape(N, T * 5))
 
 
-def build_model(backbone, H, W, N, class_num, device):
+def build_model(backbone, H, W, N, class_num, device, focal=False):
     from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
     from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
     from yolov3_tensorflow_amd.utils.radam import RAdam
@@ -55,7 +55,8 @@ def build_model(backbone, H, W, N, class_num, device):
     chans = [len(a) * L for a in COCO_ANCHORS]
     grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
     model = YOLOv3Detector(backbone).build((H, W, 3), chans, HEAD_NAMES, batch_size=N, device=device)
-    loss = YOLOv3Loss(grids, class_num, COCO_ANCHORS, 0.8, LOSS_WEIGHTS, rectified_coord_num=-1, rectified_loss_weight=[1.0, 1.0, 1.0])
+    loss = YOLOv3Loss(grids, class_num, COCO_ANCHORS, 0.8, LOSS_WEIGHTS, rectified_coord_num=-1, rectified_loss_weight=[1.0, 1.0, 1.0],
+                      is_focal_loss=focal)
     opt = RAdam(lr=1e-3)
     model.compile(optimizer=opt, loss=loss.loss)
     return model, loss, opt, grids
@@ -136,6 +137,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay two hipGraphs instead of eager two-stream launches (measured slower: the '
                     'forked weight-gradient branch is serialised under replay)')
     ap.add_argument('--no-overlap', action='store_true', help='weight-gradient GEMMs on the main stream')
+    ap.add_argument('--focal', action='store_true', help='focal loss on (BASELINE.json configs[4])')
     ap.add_argument('--no-fused-bn', action='store_true', help='three-kernel BatchNorm backward instead of the single-launch one')
     args = ap.parse_args()
 
@@ -152,7 +154,7 @@ def main():
         dist.init_process_group('nccl')
 
     H = W = args.size
-    model, loss, opt, grids = build_model(args.backbone, H, W, args.batch, args.classes, device)
+    model, loss, opt, grids = build_model(args.backbone, H, W, args.batch, args.classes, device, focal=args.focal)
     model.use_hip_graph = bool(args.graph)
     model.overlap_wgrad = not args.no_overlap
     model.g.fused_bn_bwd = not args.no_fused_bn
@@ -198,8 +200,9 @@ def main():
         'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
         'data': 'synthetic',
         'config': {'workload': '%s-YOLOv3 %dx%d, %d classes, anchors 3/3/3 (COCO-9), per-GPU batch %d, full training step '
-                               '(fwd + YOLOv3 loss + bwd + RAdam/L2%s), random-init weights'
-                               % (args.backbone, H, W, args.classes, args.batch, ' + RCCL grad all-reduce' if world > 1 else ''),
+                               '(fwd + YOLOv3 %sloss + bwd + RAdam/L2%s), random-init weights'
+                               % (args.backbone, H, W, args.classes, args.batch, 'focal ' if args.focal else '',
+                                  ' + RCCL grad all-reduce' if world > 1 else ''),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'hip_graph': bool(model.use_hip_graph),
                    'final_loss': round(final_loss, 4)},
     }

@@ -56,3 +56,31 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libyolov3_amd.so')
     with pytest.raises(_lib.YoloNativeError):
         _lib.load()
+
+
+def test_kernel_plans_are_consistent_without_gpu():
+    """host-side planning (no launches): the statistics rows of the convolution follow the kernel the tuning selects, workspaces are
+    sized, unknown tuning names are rejected"""
+    from yolov3_tensorflow_amd import ops
+    N, H, W = 32, 52, 52
+    p = ops.conv_problem(N, H, W, 128, 128, 3, 1, 'same')
+    M = N * H * W
+    try:
+        ops.set_tuning('strip_bm', 0)                      # implicit-GEMM kernel: 128-pixel tiles for this shape
+        assert ops.conv2d_stat_rows(p) == (M + 127) // 128
+        for bm in (64, 128, 256):
+            ops.set_tuning('strip_bm', bm)
+            assert ops.conv2d_stat_rows(p) == (M + bm - 1) // bm
+        ops.set_tuning('strip_bm', -1)
+        assert ops.conv2d_stat_rows(p) == (M + 127) // 128   # measured choice for 52 x 52 maps
+        p1 = ops.conv_problem(N, H, W, 128, 128, 1, 1, 'same')
+        assert ops.conv2d_stat_rows(p1) == (M + 127) // 128  # 1x1: never the strip kernel
+    finally:
+        ops.set_tuning('strip_bm', -1)
+    ws = ops.conv2d_wgrad_workspace_bytes(p)
+    assert ws % (128 * 9 * 128 * 4) == 0 and 2 <= ws // (128 * 9 * 128 * 4) <= 384     # whole slabs, one round of workgroups
+    mp = ops.mix_problem(N, 104, 104, 64, [0, 32, 48, 56, 64], [3, 5, 7, 9])
+    assert ops.dwconv_mix_wgrad_workspace_bytes(mp) > 0
+    assert ops.bn_bwd_fused_workspace_floats(512) >= (256 * 3 + 3) * 512 and ops.bn_bwd_fused_sync_words() >= 17
+    with pytest.raises(Exception):
+        ops.set_tuning('no_such_knob', 1)
