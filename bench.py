@@ -105,6 +105,24 @@ def conv_kernel_roofline(model, steps):
     return out
 
 
+def strip_hbm_traffic():
+    """HBM bytes per launch of the strip kernel: bench.py cannot run the rocprofv3 --pmc passes itself, so this is the launch-weighted
+    mean over the kernel's tile variants from the newest committed PMC summary of this same command (tools/hbm_traffic.py); the step's
+    34 launches move ~1.46 GB of activations + weights algorithmically (~43 MB per launch)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_hbm_traffic.json')))
+    for path in reversed(files):
+        try:
+            rows = [k for k in json.load(open(path))['kernels'] if k['kernel'].startswith('conv3x3_strip_kernel')]
+            n = sum(k['launches'] for k in rows)
+            if n:
+                b = sum((k['fetch_corrected_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024.0 * k['launches'] for k in rows) / n
+                return int(b), 'from profiles/' + os.path.basename(path)
+        except (KeyError, ValueError, OSError):
+            continue
+    return None, 'no PMC summary committed'
+
+
 def cpu_baseline(H, W, class_num, budget_batch=4):
     """the CPU oracle (a restatement of the reference step on PyTorch-CPU, NOT TensorFlow) timed on this host's cores"""
     from oracle.train import OracleTrainer
@@ -212,9 +230,11 @@ def main():
     if rank == 0 and not args.no_roofline:
         rf = conv_kernel_roofline(model, max(2, min(5, args.steps)))
         tf, avg_ms, per_step = rf['strip']
+        traffic, traffic_src = strip_hbm_traffic()
         out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel (3x3 stride-1 conv forward + data-gradient launches, all tile variants)',
                            'achieved': round(tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_TFLOPS, 4),
-                           'traffic': None, 'avg_launch_ms': round(avg_ms, 5), 'launches_per_step': per_step,
+                           'traffic': traffic, 'traffic_unit': 'bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), ' + traffic_src,
+                           'avg_launch_ms': round(avg_ms, 5), 'launches_per_step': per_step,
                            'other_conv': {'kernel': 'igemm_fwd_kernel (stem, stride-2, 1x1, fused-concat launches)',
                                           'achieved': round(rf['other'][0], 2), 'avg_launch_ms': round(rf['other'][1], 5),
                                           'launches_per_step': rf['other'][2]}}
