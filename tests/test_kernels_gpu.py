@@ -206,6 +206,39 @@ def test_wgrad_strip_matches_generic(dev, shape):
         torch.testing.assert_close(t, ref[1], rtol=1e-4, atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize('shape', [(3, 12, 20, 64, 128), (2, 11, 9, 128, 64), (2, 26, 26, 128, 256)])
+def test_stride2_dgrad_parity_classes_match_strided_gather(dev, shape):
+    """stride-2 data gradient: the four-parity-class launch (default) against the strided den = 2 gather (fallback path, still used for
+    kernel sizes other than 3) on even and odd maps, overwrite and fan-in accumulate"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(17)
+    N, H, W, Cin, Cout = shape
+    p = ops.conv_problem(N, H, W, Cin, Cout, 3, 2, 'same')
+    w = bf(torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).to(dev)
+    dy = bf(torch.randn(N, p.Ho, p.Wo, Cout, generator=g)).to(dev)
+    base = bf(torch.randn(N, H, W, Cin, generator=g)).to(dev)
+    w_dg = torch.empty(Cin, 3, 3, Cout, dtype=torch.bfloat16, device=dev)
+    ops.repack_dgrad_weights(w, w_dg, Cout, 3, 3, Cin)
+
+    def run():
+        dx = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
+        ops.conv2d_dgrad(p, dy, w_dg, dx)
+        acc = base.clone()
+        ops.conv2d_dgrad(p, dy, w_dg, acc, accumulate=True)
+        torch.cuda.synchronize()
+        return dx.float().cpu(), acc.float().cpu()
+
+    try:
+        ops.set_tuning('s2_classes', 0)
+        ref = run()
+        ops.set_tuning('s2_classes', 1)
+        got = run()
+    finally:
+        ops.set_tuning('s2_classes', 1)
+    for a, b in zip(got, ref):       # same products, different summation order: within a bf16 ulp
+        torch.testing.assert_close(a, b, rtol=2 ** -7, atol=2e-3)
+
+
 def test_conv_fused_upsample_concat(dev):
     """1x1 conv over concat(upsample2x(a), b) without materialising the concat (yolov3_detector.py:115-118)"""
     from yolov3_tensorflow_amd import ops
