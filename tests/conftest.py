@@ -8,3 +8,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _drain_gpu_after_test():
+    """GPU tests leave no queued work behind: a kernel of a finished test must not run into the next test's freshly allocated tensors"""
+    yield
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass

@@ -371,8 +371,11 @@ __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed once at most the loads of stages kt+1 .. kt+NSTAGE-2 are outstanding (vmcnt counts in issue order);
     // in the last NSTAGE-2 iterations fewer stages are in flight, so drain completely there
-    if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPS) : "memory");
-    else                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lgkmcnt(0): this wave's LDS reads of stage kt-1 must have COMPLETED before the barrier lets other waves' LDS-DMA refill that
+    // buffer -- the compiler happily sinks the lgkmcnt wait (and the last MFMAs of the previous stage) below a raw s_barrier, and a
+    // DMA write does not queue behind another wave's pending ds_read (seen as a rare corrupted half tile)
+    if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPS) : "memory");
+    else                      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // every wave's part of stage kt is visible; stage kt-1 is no longer read
     asm volatile("" ::: "memory");
     if (kt + NSTAGE - 1 < nk) issue_stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);   // refills the buffer of stage kt-1
@@ -516,13 +519,18 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, con
     if (q < nk) issue_next();
   int kk = 0, cstage = 0;
   for (int cc = 0; cc < nchunk; ++cc) {
-    if (cc > 0) __builtin_amdgcn_s_barrier();          // every wave has finished reading the previous slice's strip
+    if (cc > 0) {                                       // every wave has finished reading the previous slice's strip (reads completed)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     issue_strip(cc);
     for (int tr = 0; tr < 3; ++tr)
       for (int ts = 0; ts < 3; ++ts, ++kk) {
         // weight stage kk (and, on the first tap of a slice, the strip issued after the prefetched stages) must have landed
-        if (WS == 2 || (tr | ts) == 0 || kk + WS - 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else                                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WS - 2) * B_INSTR) : "memory");
+        // (lgkmcnt(0): the reads of the stage that is refilled after this barrier have completed -- see igemm_fwd_kernel)
+        if (WS == 2 || (tr | ts) == 0 || kk + WS - 2 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else                                                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((WS - 2) * B_INSTR) : "memory");
         __builtin_amdgcn_s_barrier();                  // strip + weight stage kk visible; the stage of K-step kk-1 is no longer read
         asm volatile("" ::: "memory");
         if (kk + WS - 1 < nk) issue_next();
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(Gather g, const bf
   issue_stage(s_begin, 0);
   for (int st = s_begin; st < s_end; ++st) {
     const int buf = (st - s_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // loads landed; this wave's reads of the buffer refilled next completed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (st + 1 < s_end) issue_stage(st + 1, buf ^ 1);
@@ -879,7 +887,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, f
   issue_stage(0);
   for (int st = s_begin; st < s_end; ++st) {
     const int buf = (st - s_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // loads landed; this wave's reads of the buffer refilled next completed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (st + 1 < s_end) issue_stage(buf ^ 1);

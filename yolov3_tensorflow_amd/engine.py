@@ -435,6 +435,36 @@ class Graph(object):
         if side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(side)
 
+    def owned_tensors(self):
+        """every device tensor this graph (its parameter store, ops and BatchNorm states) holds"""
+        seen, out = set(), []
+
+        def visit(obj, depth):
+            if isinstance(obj, torch.Tensor):
+                if obj.is_cuda and obj.data_ptr() not in seen:
+                    seen.add(obj.data_ptr())
+                    out.append(obj)
+            elif isinstance(obj, dict) and depth < 3:
+                for v in obj.values():
+                    visit(v, depth + 1)
+            elif isinstance(obj, (list, tuple)) and depth < 3:
+                for v in obj:
+                    visit(v, depth + 1)
+            elif hasattr(obj, '__dict__') and depth < 3 and not isinstance(obj, Graph):
+                for v in vars(obj).values():
+                    visit(v, depth + 1)
+
+        for v in vars(self).values():
+            visit(v, 0)
+        return out
+
+    def use_side_stream(self, stream):
+        """tell the caching allocator that the graph's buffers are also used on `stream` (weight-gradient kernels, the asynchronous
+        data-gradient weight repack): when the graph is dropped while such work is still queued, the memory is not handed to the next
+        allocation until that work has finished (without this a following tensor could be scribbled on by a late kernel)"""
+        for t in self.owned_tensors():
+            t.record_stream(stream)
+
     def refresh_dgrad_async(self):
         """refresh_dgrad_weights on the weight-gradient stream (eager mode): the copies are first needed by the NEXT step's backward pass,
         so the repack overlaps the next forward instead of sitting between the optimizer and it"""

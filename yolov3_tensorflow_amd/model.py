@@ -83,6 +83,10 @@ class YOLOv3Model(object):
         g = self.g
         if self.overlap_wgrad and g.wgrad_stream is None:
             g.wgrad_stream = torch.cuda.Stream(device=self.device)
+            g.use_side_stream(g.wgrad_stream)
+            for t in (getattr(self.loss_obj, '__dict__', {}) or {}).values():
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(g.wgrad_stream)
         elif not self.overlap_wgrad:
             g.wgrad_stream = None
         g.run_forward()
