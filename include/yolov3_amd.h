@@ -218,6 +218,25 @@ int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_global, const 
 int yolo_decode_head(const float* logits, int N, int H, int W, int B, int L, int ldc, const float* anchors_grid, float eps, float* decoded,
                      float* boxes, float* score, int* cls_idx, void* stream);
 
+/* inference-side box selection, per head: YOLOv3PostProcessor._filter_single_head_boxes
+ * (/root/reference/yolov3/yolov3_post_process.py:45-77).  prediction: decoded float32 [N][H][W][B][L] (what yolo_decode_head writes),
+ * boxes: corners [N][H][W][B][4] in grid units.  For each image, every prediction with score = conf * max class prob (conf alone
+ * when L == 5) > score_thresh is appended in flat (row, col, anchor) order -- np.where order -- to rows[n][k][8] =
+ * {x0/W, y0/H, x1/W, y1/H, conf, class prob, class index, score} (float32 arithmetic as in the reference) and its flat index to
+ * index[n][k]; counts[n] = number of hits, which may exceed cap (only the first cap are stored: the caller must check). */
+int yolo_filter_boxes(const float* prediction, const float* boxes, int N, int H, int W, int B, int L, float score_thresh, int cap,
+                      int* counts, float* rows, int* index, void* stream);
+/* cross-head class-wise greedy NMS: YOLOv3PostProcessor.apply_nms / _apply_nms / _cal_iou (yolov3_post_process.py:79-162), one
+ * workgroup per image over the rows of yolo_filter_boxes for the three heads: stable sort by descending score over the
+ * concatenation /8, /16, /32; a box is suppressed by a better box of the same class whose IoU (float64, no fma) > nms_thresh;
+ * keepX[n][k] = 1 iff row k's id is among the survivors' ids.  Ids are per-head positions, as in the reference (start_index is
+ * never advanced, :81-89), unless fixed_indices.  If an image has more than yolo_nms_max_candidates() rows in total, or a count
+ * exceeds cap, nothing is written for it and *status (device int32, zero it first) receives the offending count. */
+int yolo_nms_max_candidates(void);
+int yolo_nms_heads(const float* rows8, const float* rows16, const float* rows32, const int* count8, const int* count16, const int* count32,
+                   int N, int cap, double nms_thresh, int fixed_indices, uint8_t* keep8, uint8_t* keep16, uint8_t* keep32, int* status,
+                   void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * RAdam + L2 regularisation over the flat parameter buffer.  Replaces RAdam.get_updates
  * (/root/reference/utils/radam.py:56-107) and the Keras L2 regularisers (/root/reference/backbone/basic_backbone.py:41,64,76).

@@ -76,6 +76,9 @@ SIGNATURES = {
     'yolo_loss_workspace_bytes': (I64, [LP, I]),
     'yolo_loss_fwd_bwd': (I, [LP, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'yolo_decode_head': (I, [P, I, I, I, I, I, I, P, F, P, P, P, P, P]),
+    'yolo_filter_boxes': (I, [P, P, I, I, I, I, I, F, I, P, P, P, P]),
+    'yolo_nms_max_candidates': (I, []),
+    'yolo_nms_heads': (I, [P, P, P, P, P, P, I, I, C.c_double, I, P, P, P, P, P]),
     'yolo_radam_schedule': (I, [P, P, F, F, F, F, P]),
     'yolo_radam_l2_blocks': (I, [I64]),
     'yolo_radam_l2_step': (I, [P, P, P, P, P, P, P, I64, P, F, F, F, F, I, P, P]),

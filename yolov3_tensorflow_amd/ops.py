@@ -295,6 +295,21 @@ def decode_head(logits, N, H, W, B, L, ldc, anchors_grid, eps, decoded=None, box
                                        _stream()), 'yolo_decode_head')
 
 
+def filter_boxes(prediction, boxes, N, H, W, B, L, score_thresh, cap, counts, rows, index):
+    check(_lib.load().yolo_filter_boxes(_p(prediction), _p(boxes), N, H, W, B, L, float(score_thresh), cap, _p(counts), _p(rows), _p(index),
+                                        _stream()), 'yolo_filter_boxes')
+
+
+def nms_max_candidates():
+    return _lib.load().yolo_nms_max_candidates()
+
+
+def nms_heads(rows, counts, N, cap, nms_thresh, fixed_indices, keep, status):
+    check(_lib.load().yolo_nms_heads(_p(rows[0]), _p(rows[1]), _p(rows[2]), _p(counts[0]), _p(counts[1]), _p(counts[2]), N, cap,
+                                     float(nms_thresh), int(fixed_indices), _p(keep[0]), _p(keep[1]), _p(keep[2]), _p(status), _stream()),
+          'yolo_nms_heads')
+
+
 def radam_schedule(sched, iterations, beta1, beta2, decay, warmup_coef):
     check(_lib.load().yolo_radam_schedule(_p(sched), _p(iterations), beta1, beta2, decay, warmup_coef, _stream()), 'yolo_radam_schedule')
 

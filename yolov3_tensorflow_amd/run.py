@@ -27,8 +27,22 @@ def train(yolov3_trainer):
 
 
 def _detect(yolov3_trainer, yolov3_decoder, images):
-    predictions = yolov3_trainer.predict(images)
-    return yolov3_decoder.decode(predictions)
+    """network + decode + score filter + NMS (reference :60-72) without leaving the GPU: forward kernels -> yolo_decode_head ->
+    yolo_filter_boxes -> yolo_nms_heads; only the surviving rows come back.  -> per image [head /8, /16, /32] (k, 9) arrays"""
+    model = yolov3_trainer.model
+    images = np.asarray(images, dtype=np.float32)
+    n, N = images.shape[0], model.batch_size
+    out = []
+    for i in range(0, n, N):
+        chunk = images[i:i + N]
+        valid = chunk.shape[0]
+        if valid < N:
+            chunk = np.concatenate([chunk, np.zeros((N - valid,) + chunk.shape[1:], np.float32)], axis=0)
+        decoded, boxes = yolov3_decoder.decode_device(model.forward_only(chunk, training=False))
+        dev_boxes = YOLOv3PostProcessor.filter_boxes_device(decoded, boxes, FLAGS.confidence_thresh)
+        YOLOv3PostProcessor.apply_nms_device(dev_boxes, FLAGS.nms_thresh)
+        out.extend(YOLOv3PostProcessor.boxes_to_host(dev_boxes)[:valid])
+    return out
 
 
 def test(yolov3_trainer, yolov3_decoder, save_path=None):
@@ -38,11 +52,9 @@ def test(yolov3_trainer, yolov3_decoder, save_path=None):
     input_box_size = np.tile(FLAGS.input_image_size[1::-1], [2])          # [W, H, W, H]
     results = []
     for images, labels, image_paths in test_set:
-        heads = _detect(yolov3_trainer, yolov3_decoder, images)
+        detections = _detect(yolov3_trainer, yolov3_decoder, images)
         for n, (image, image_path) in enumerate(zip(images, image_paths)):
-            hs = YOLOv3PostProcessor.filter_boxes(heads[0][1][n], heads[0][2][n], heads[1][1][n], heads[1][2][n], heads[2][1][n],
-                                                  heads[2][2][n], FLAGS.confidence_thresh)
-            nms_boxes = YOLOv3PostProcessor.apply_nms(hs, FLAGS.nms_thresh)
+            nms_boxes = detections[n]
             in_boxes = YOLOv3PostProcessor.resize_boxes(nms_boxes, target_size=input_box_size)
             results.append((image_path, in_boxes))
             if save_path is not None:
@@ -59,10 +71,8 @@ def predict(yolov3_trainer, yolov3_decoder, image_paths, save_path):
         rgb = np.asarray(Image.open(image_path).convert('RGB'))
         boxed, _ = FileUtil.letterbox(rgb, np.zeros((0, 5), np.float32), FLAGS.input_image_size[0:2])
         image = (boxed.astype(np.float32) / 255.0)[..., ::-1]
-        heads = _detect(yolov3_trainer, yolov3_decoder, np.expand_dims(image, 0))
-        hs = YOLOv3PostProcessor.filter_boxes(heads[0][1][0], heads[0][2][0], heads[1][1][0], heads[1][2][0], heads[2][1][0], heads[2][2][0],
-                                              FLAGS.confidence_thresh)
-        in_boxes = YOLOv3PostProcessor.resize_boxes(YOLOv3PostProcessor.apply_nms(hs, FLAGS.nms_thresh), target_size=input_box_size)
+        nms_boxes = _detect(yolov3_trainer, yolov3_decoder, np.expand_dims(image, 0))[0]
+        in_boxes = YOLOv3PostProcessor.resize_boxes(nms_boxes, target_size=input_box_size)
         YOLOv3PostProcessor.visualize(image, in_boxes, src_box_size=input_box_size, image_path=os.path.join(save_path, os.path.basename(image_path)))
 
 

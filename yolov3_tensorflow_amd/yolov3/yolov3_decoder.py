@@ -28,6 +28,21 @@ class YOLOv3Decoder(object):
             start = end
         return out
 
+    def decode_device(self, head_logits, ldc=None):
+        """the same decode without leaving the GPU: ``head_logits`` = the detector's three float32 device tensors (N, H, W, ldc) (row
+        stride ldc >= B*L) -> ([decoded (N,H,W,B,L)] x 3, [boxes (N,H,W,B,4)] x 3) device tensors for
+        YOLOv3PostProcessor.filter_boxes_device"""
+        decoded, boxes = [], []
+        for lg, (h, w), b, anc in zip(head_logits, self.head_grid_sizes, self.box_num, self.anchors):
+            N, L = lg.shape[0], self.box_len
+            row = int(ldc) if ldc is not None else lg.shape[-1]
+            assert lg.dtype == torch.float32 and lg.is_contiguous() and lg.shape[1:3] == (h, w) and row >= b * L
+            dec = torch.empty(N, h, w, b, L, device=lg.device)
+            box = torch.empty(N, h, w, b, 4, device=lg.device)
+            ops.decode_head(lg, N, h, w, b, L, row, torch.as_tensor(anc).to(lg.device), backend.epsilon(), decoded=dec, boxes=box)
+            decoded.append(dec), boxes.append(box)
+        return decoded, boxes
+
     def decode(self, predicts, with_scores=False):
         """reference :62-87 -> [(raw t_xywh (N,H,W,B,4), decoded (N,H,W,B,L), boxes (N,H,W,B,4))] x 3, order /8, /16, /32.
         with_scores=True appends (score (N,H,W,B), class index (N,H,W,B)) computed on the GPU."""

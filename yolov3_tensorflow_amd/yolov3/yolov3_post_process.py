@@ -5,6 +5,14 @@ never-advanced ``start_index`` (:81-89) by default; ``fixed_indices=True`` gives
 import numpy as np
 
 
+class DeviceBoxes(object):
+    """candidate rows of one batch on the GPU: per head rows (N, cap, 8) float32, counts (N,) int32, flat prediction index (N, cap) int32,
+    keep flags (N, cap) uint8 (after apply_nms_device)"""
+
+    def __init__(self, rows, counts, index, cap):
+        self.rows, self.counts, self.index, self.cap, self.keep, self.fixed_indices = rows, counts, index, cap, None, False
+
+
 class YOLOv3PostProcessor(object):
     HEAD_BOX_COLOR = [[255, 0, 0], [0, 255, 0], [0, 0, 255]]  # blue, green, red (BGR) for head /8, /16, /32
 
@@ -96,6 +104,62 @@ class YOLOv3PostProcessor(object):
     def _overlap(x1, x2, x3, x4):
         """reference :150-162"""
         return min(x2, x4) - max(x1, x3)
+
+    # ------------------------------------------------------------------------------------------------ GPU path (whole batch)
+    @staticmethod
+    def filter_boxes_device(predictions, boxes, score_thresh, cap=1024):
+        """batched _filter_single_head_boxes on the GPU (yolo_filter_boxes): ``predictions`` / ``boxes`` are the three decoded device
+        tensors (N, H, W, B, L) / (N, H, W, B, 4) of YOLOv3Decoder.decode_device.  Raises if an image has more than ``cap`` hits."""
+        import torch
+        from yolov3_tensorflow_amd import ops
+        rows, counts, index = [], [], []
+        for pred, box in zip(predictions, boxes):
+            N, H, W, B, L = pred.shape
+            r = torch.empty(N, cap, 8, device=pred.device)
+            c = torch.empty(N, dtype=torch.int32, device=pred.device)
+            ix = torch.empty(N, cap, dtype=torch.int32, device=pred.device)
+            ops.filter_boxes(pred, box, N, H, W, B, L, np.float32(score_thresh), cap, c, r, ix)
+            rows.append(r), counts.append(c), index.append(ix)
+        return DeviceBoxes(rows, counts, index, cap)
+
+    @staticmethod
+    def apply_nms_device(dev_boxes, nms_thresh, fixed_indices=False):
+        """apply_nms for every image of the batch in one launch (yolo_nms_heads)"""
+        import torch
+        from yolov3_tensorflow_amd import ops
+        N = dev_boxes.counts[0].shape[0]
+        dev = dev_boxes.counts[0].device
+        keep = [torch.zeros(N, dev_boxes.cap, dtype=torch.uint8, device=dev) for _ in range(3)]
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.nms_heads(dev_boxes.rows, dev_boxes.counts, N, dev_boxes.cap, nms_thresh, fixed_indices, keep, status)
+        bad = int(status.item())
+        if bad:
+            raise RuntimeError('box selection overflow: an image has %d candidate boxes (cap %d per head, %d per image); raise the score '
+                               'threshold or the cap' % (bad, dev_boxes.cap, ops.nms_max_candidates()))
+        dev_boxes.keep, dev_boxes.fixed_indices = keep, bool(fixed_indices)
+        return dev_boxes
+
+    @staticmethod
+    def boxes_to_host(dev_boxes, after_nms=True):
+        """-> per image [head /8, /16, /32] float64 arrays in the reference's row format: (k, 8) filtered rows, or (k, 9) rows with the
+        box id appended for the NMS survivors (what apply_nms returns)"""
+        counts = [c.cpu().numpy() for c in dev_boxes.counts]
+        rows = [r.cpu().numpy() for r in dev_boxes.rows]
+        keep = [k.cpu().numpy().astype(bool) for k in dev_boxes.keep] if after_nms else None
+        out = []
+        for n in range(counts[0].shape[0]):
+            per_head, start = [], 0
+            for h in range(3):
+                k = int(counts[h][n])
+                if k > dev_boxes.cap:
+                    raise RuntimeError('box selection overflow: %d hits in one head (cap %d)' % (k, dev_boxes.cap))
+                r = rows[h][n, :k].astype(np.float64)
+                if after_nms:
+                    r = np.concatenate([r, np.arange(start, start + k, dtype=np.float64)[:, None]], axis=-1)[keep[h][n, :k]]
+                    start += k if dev_boxes.fixed_indices else 0
+                per_head.append(r)
+            out.append(per_head)
+        return out
 
     @staticmethod
     def resize_boxes(boxes, target_size):
