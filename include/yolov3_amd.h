@@ -238,6 +238,29 @@ int yolo_nms_heads(const float* rows8, const float* rows16, const float* rows32,
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Input pipeline (the row before the hot path).  Replaces, for one batch of decoded images,
+ * tf.image.resize_image_with_pad(NEAREST) + convert_image_dtype + tf.reverse (/root/reference/dataset/file_util.py:54-59) and
+ * DatasetUtil._augment (/root/reference/dataset/dataset_util.py:29-99).  JPEG decoding stays on the host.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int64_t offset;            /* byte offset of this image's uint8 RGB HWC pixels in src */
+  int32_t h, w;              /* decoded size */
+  int32_t nh, nw, top, left; /* letterbox geometry: resized size and position inside the H x W canvas (bars are zero) */
+  int32_t noise;             /* 0 salt-and-pepper p = 0.01, 1 gaussian sigma = 0.01, anything else none (dataset_util.py:47-56) */
+  int32_t color_order;       /* 0 brightness,saturation,contrast; 1 saturation,brightness,contrast; 2 saturation,contrast,brightness;
+                                anything else none (dataset_util.py:58-96) */
+  float brightness_delta, saturation_factor, contrast_factor;   /* the scalar draws of tf.image.random_* (host side) */
+  uint32_t seed0, seed1;     /* Philox4x32-10 key of the per-pixel noise; counter = (pixel index, image index, 0, 0) */
+  int32_t reserved;
+} yolo_image_desc;
+
+int64_t yolo_letterbox_workspace_bytes(int N);
+/* src: device uint8; desc: device array [N].  out_f32 (float32 [N][H][W][3], BGR in [0,1]) and / or out_bf16x8 (the packed conv input
+ * [N][H][W][8], channels 3..7 zero) -- at least one.  augment = 0 skips noise / colour / clip (test and predict modes). */
+int yolo_letterbox_augment(const uint8_t* src, const yolo_image_desc* desc, int N, int H, int W, int augment, void* workspace,
+                           float* out_f32, void* out_bf16x8, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * RAdam + L2 regularisation over the flat parameter buffer.  Replaces RAdam.get_updates
  * (/root/reference/utils/radam.py:56-107) and the Keras L2 regularisers (/root/reference/backbone/basic_backbone.py:41,64,76).
  * sched: device float32 [4] = {lr (host-set), lr_t, rho_t, adaptive}; iterations: device int64 [1].

@@ -26,22 +26,55 @@ def test_product_postprocessor_matches_reference_goldens(path):
 
 
 def test_letterbox_and_label_transform():
-    from yolov3_tensorflow_amd.dataset.file_util import FileUtil
+    """oracle letterbox (the published resize_image_with_pad / nearest-neighbour algorithm), the product's geometry and label transform"""
+    from oracle import dataset as ods
+    from yolov3_tensorflow_amd.dataset.file_util import FileUtil, DeviceImagePipeline
     img = np.zeros((100, 200, 3), np.uint8)
     img[:, :, 0] = np.arange(200)[None, :]
     lab = np.array([[0.5, 0.5, 0.2, 0.4, 3.0], [0.1, 0.9, 0.1, 0.1, 1.0]], np.float32)
-    out, l2 = FileUtil.letterbox(img, lab, (160, 160))
+    out = ods.letterbox(img, (160, 160))
     assert out.shape == (160, 160, 3)
     assert out[:40].sum() == 0 and out[120:].sum() == 0 and out[40:120].any()          # 200x100 -> 160x80 centred, 40 px bars
     np.testing.assert_array_equal(out[40, :, 0], (np.arange(160) * 200 // 160).astype(np.uint8))   # nearest neighbour columns
+    assert DeviceImagePipeline.geometry(100, 200, 160, 160) == (80, 160, 40, 0) == ods.letterbox_geometry(100, 200, 160, 160)
+    assert DeviceImagePipeline.geometry(500, 353, 320, 320) == (320, 225, 0, 47)       # floor(225.92), floor((320 - 225.92) / 2)
     # xy' = xy*r + (1-r)/2, wh' = wh*r with r = (1, 0.5) for (x, y) (dataset/file_util.py:47-55)
+    l2 = FileUtil.transform_label(lab, (100, 200), (160, 160))
     np.testing.assert_allclose(l2[0], [0.5, 0.5, 0.2, 0.2, 3.0], rtol=1e-6)
     np.testing.assert_allclose(l2[1], [0.1, 0.7, 0.1, 0.05, 1.0], rtol=1e-6)
+    np.testing.assert_array_equal(l2, ods.transform_label(lab, 100, 200, (160, 160)))
+
+
+def test_augmentation_oracle_properties():
+    """oracle/dataset.py: Philox known-answer vectors (Random123 kat_vectors), noise rates, and the colour ops' identities"""
+    from oracle import dataset as ods
+    kat = ods.philox4x32(np.array([[0, 0, 0, 0], [0xffffffff] * 4, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], np.uint32),
+                         np.array([0, 0], np.uint32))[0]
+    np.testing.assert_array_equal(kat, np.array([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], np.uint32))
+    k2 = ods.philox4x32(np.array([[0xffffffff] * 4], np.uint32), np.array([0xffffffff, 0xffffffff], np.uint32))[0]
+    np.testing.assert_array_equal(k2, np.array([0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd], np.uint32))
+    k3 = ods.philox4x32(np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], np.uint32), np.array([0xa4093822, 0x299f31d0], np.uint32))[0]
+    np.testing.assert_array_equal(k3, np.array([0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1], np.uint32))
+    rng = np.random.RandomState(0)
+    img = rng.uniform(0.05, 0.95, size=(96, 128, 3)).astype(np.float32)
+    sp = ods.pixel_noise(img, 0, (1, 2), 0)
+    changed = (sp != img).any(-1)
+    assert 0.004 < changed.mean() < 0.02 and set(np.unique(sp[changed])) <= {0.0, 1.0}
+    ga = ods.pixel_noise(img, 1, (1, 2), 0) - img
+    assert abs(ga.std() - 0.01) < 1e-3 and abs(ga.mean()) < 3e-4
+    np.testing.assert_allclose(ods.adjust_saturation(img, 1.0), img, atol=2e-6)          # HSV round trip
+    grey = ods.adjust_saturation(img, 0.0)
+    np.testing.assert_allclose(grey, np.repeat(img.max(-1, keepdims=True), 3, -1), atol=1e-6)     # S = 0 -> (V, V, V)
+    out = ods.augment(img, 2, 2, 0.05, 1.0, 1.0, (0, 0), 0)                              # only brightness acts
+    np.testing.assert_allclose(out, np.clip(img + np.float32(0.05), 0, 1), atol=2e-6)
+    out = ods.augment(img, 2, 3, 0.05, 1.1, 0.9, (0, 0), 0)                              # order 3: nothing but the clip
+    np.testing.assert_array_equal(out, img)
 
 
 def test_dataset_iterator_shapes(tmp_path):
     from PIL import Image
     from yolov3_tensorflow_amd.dataset.file_util import FileUtil
+    from yolov3_tensorflow_amd.dataset.dataset_util import DatasetUtil
     rng = np.random.default_rng(0)
     lines = []
     for i in range(5):
@@ -49,13 +82,17 @@ def test_dataset_iterator_shapes(tmp_path):
         k = 1 + i % 3
         lines.append('%d.jpg ' % i + ' '.join('0.5 0.5 0.2 0.2 %d' % j for j in range(k)))
     (tmp_path / 'label.txt').write_text('\n'.join(lines) + '\n')
-    it = FileUtil.get_dataset(str(tmp_path / 'label.txt'), str(tmp_path), (64, 64), 2, is_augment=True, is_test=False)
+    it = FileUtil.host_batches(str(tmp_path / 'label.txt'), str(tmp_path), (64, 64), 2, is_augment=True, is_test=False)
     for _ in range(4):                                   # infinite, always full batches (reference file_util.py:79)
-        x, y = next(it)
-        assert x.shape == (2, 64, 64, 3) and x.dtype == np.float32 and 0.0 <= x.min() and x.max() <= 1.0
+        imgs, y, draws, paths = next(it)
+        assert len(imgs) == 2 and all(im.dtype == np.uint8 and im.shape[1:] == (60, 3) for im in imgs) and len(paths) == 2
         assert y.shape == (2, 15) and ((y == -1) | (y >= 0)).all()
-    test_batches = list(FileUtil.get_dataset(str(tmp_path / 'label.txt'), str(tmp_path), (64, 64), 2, is_augment=False, is_test=True))
-    assert len(test_batches) == 3 and len(test_batches[0]) == 3 and len(test_batches[0][2]) == 2
+        assert len(draws) == 2 and all(d['noise'] in (0, 1, 2) and d['color_order'] in (0, 1, 2, 3) and
+                                       abs(d['brightness_delta']) <= DatasetUtil._random_brightness and
+                                       0.9 <= d['saturation_factor'] <= 1.1 and 0.9 <= d['contrast_factor'] <= 1.1 for d in draws)
+    test_batches = list(FileUtil.host_batches(str(tmp_path / 'label.txt'), str(tmp_path), (64, 64), 2, is_augment=False, is_test=True))
+    assert all(b[2] is None for b in test_batches)       # no augmentation draws in test mode
+    assert len(test_batches) == 3 and len(test_batches[0]) == 4 and len(test_batches[0][3]) == 2
 
 
 def test_label_decoder_matches_oracle():

@@ -30,6 +30,13 @@ class LossConfig(C.Structure):
                 ('focal_alpha', C.c_float), ('focal_gamma', C.c_float), ('is_tiou_recall', C.c_int32), ('eps', C.c_float)]
 
 
+class ImageDesc(C.Structure):
+    _fields_ = [('offset', C.c_int64), ('h', C.c_int32), ('w', C.c_int32), ('nh', C.c_int32), ('nw', C.c_int32), ('top', C.c_int32),
+                ('left', C.c_int32), ('noise', C.c_int32), ('color_order', C.c_int32), ('brightness_delta', C.c_float),
+                ('saturation_factor', C.c_float), ('contrast_factor', C.c_float), ('seed0', C.c_uint32), ('seed1', C.c_uint32),
+                ('reserved', C.c_int32)]
+
+
 P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 CP = C.POINTER(ConvProblem)
 MP = C.POINTER(MixProblem)
@@ -79,6 +86,8 @@ SIGNATURES = {
     'yolo_filter_boxes': (I, [P, P, I, I, I, I, I, F, I, P, P, P, P]),
     'yolo_nms_max_candidates': (I, []),
     'yolo_nms_heads': (I, [P, P, P, P, P, P, I, I, C.c_double, I, P, P, P, P, P]),
+    'yolo_letterbox_workspace_bytes': (I64, [I]),
+    'yolo_letterbox_augment': (I, [P, P, I, I, I, I, P, P, P, P]),
     'yolo_radam_schedule': (I, [P, P, F, F, F, F, P]),
     'yolo_radam_l2_blocks': (I, [I64]),
     'yolo_radam_l2_step': (I, [P, P, P, P, P, P, P, I64, P, F, F, F, F, I, P, P]),

@@ -310,6 +310,18 @@ def nms_heads(rows, counts, N, cap, nms_thresh, fixed_indices, keep, status):
           'yolo_nms_heads')
 
 
+def letterbox_workspace_bytes(N):
+    r = _lib.load().yolo_letterbox_workspace_bytes(N)
+    if r < 0:
+        raise _lib.YoloNativeError('yolo_letterbox_workspace_bytes(%d) rejected' % N)
+    return r
+
+
+def letterbox_augment(src, desc, N, H, W, augment, workspace, out_f32=None, out_bf16x8=None):
+    check(_lib.load().yolo_letterbox_augment(_p(src), _p(desc), N, H, W, int(augment), _p(workspace), _p(out_f32), _p(out_bf16x8), _stream()),
+          'yolo_letterbox_augment')
+
+
 def radam_schedule(sched, iterations, beta1, beta2, decay, warmup_coef):
     check(_lib.load().yolo_radam_schedule(_p(sched), _p(iterations), beta1, beta2, decay, warmup_coef, _stream()), 'yolo_radam_schedule')
 

@@ -29,15 +29,17 @@ def train(yolov3_trainer):
 def _detect(yolov3_trainer, yolov3_decoder, images):
     """network + decode + score filter + NMS (reference :60-72) without leaving the GPU: forward kernels -> yolo_decode_head ->
     yolo_filter_boxes -> yolo_nms_heads; only the surviving rows come back.  -> per image [head /8, /16, /32] (k, 9) arrays"""
+    import torch
     model = yolov3_trainer.model
-    images = np.asarray(images, dtype=np.float32)
+    if not torch.is_tensor(images):
+        images = torch.as_tensor(np.asarray(images, dtype=np.float32))
     n, N = images.shape[0], model.batch_size
     out = []
     for i in range(0, n, N):
         chunk = images[i:i + N]
         valid = chunk.shape[0]
         if valid < N:
-            chunk = np.concatenate([chunk, np.zeros((N - valid,) + chunk.shape[1:], np.float32)], axis=0)
+            chunk = torch.cat([chunk, torch.zeros((N - valid,) + tuple(chunk.shape[1:]), dtype=chunk.dtype, device=chunk.device)], dim=0)
         decoded, boxes = yolov3_decoder.decode_device(model.forward_only(chunk, training=False))
         dev_boxes = YOLOv3PostProcessor.filter_boxes_device(decoded, boxes, FLAGS.confidence_thresh)
         YOLOv3PostProcessor.apply_nms_device(dev_boxes, FLAGS.nms_thresh)
@@ -58,19 +60,18 @@ def test(yolov3_trainer, yolov3_decoder, save_path=None):
             in_boxes = YOLOv3PostProcessor.resize_boxes(nms_boxes, target_size=input_box_size)
             results.append((image_path, in_boxes))
             if save_path is not None:
-                YOLOv3PostProcessor.visualize(image, in_boxes, src_box_size=input_box_size,
+                YOLOv3PostProcessor.visualize(image.cpu().numpy() if hasattr(image, 'cpu') else image, in_boxes, src_box_size=input_box_size,
                                               image_path=os.path.join(save_path, os.path.basename(image_path)))
     return results
 
 
 def predict(yolov3_trainer, yolov3_decoder, image_paths, save_path):
     """reference :83-120"""
-    from PIL import Image
+    from yolov3_tensorflow_amd.dataset.file_util import DeviceImagePipeline
     input_box_size = np.tile(FLAGS.input_image_size[1::-1], [2])
+    pipe = DeviceImagePipeline(1, FLAGS.input_image_size[0:2])
     for image_path in image_paths:
-        rgb = np.asarray(Image.open(image_path).convert('RGB'))
-        boxed, _ = FileUtil.letterbox(rgb, np.zeros((0, 5), np.float32), FLAGS.input_image_size[0:2])
-        image = (boxed.astype(np.float32) / 255.0)[..., ::-1]
+        image = pipe([FileUtil.read_image(image_path)]).cpu().numpy()[0]       # letterbox, x/255, RGB -> BGR on the GPU
         nms_boxes = _detect(yolov3_trainer, yolov3_decoder, np.expand_dims(image, 0))[0]
         in_boxes = YOLOv3PostProcessor.resize_boxes(nms_boxes, target_size=input_box_size)
         YOLOv3PostProcessor.visualize(image, in_boxes, src_box_size=input_box_size, image_path=os.path.join(save_path, os.path.basename(image_path)))
