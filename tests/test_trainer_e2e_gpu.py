@@ -1,0 +1,84 @@
+"""End to end through the reference-shaped surface on the GPU: FileUtil.get_dataset (GPU input pipeline) -> YOLOv3Trainer.train
+(callbacks: checkpoints with the reference's file naming, TensorBoard event files, detail log) -> reload -> run.test (GPU decode, box
+selection, NMS, visualisation)."""
+import glob
+import logging
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_checkpoint_tensorboard_and_test_mode(tmp_path, caplog):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from PIL import Image
+    from yolov3_tensorflow_amd import configs
+    from yolov3_tensorflow_amd.configs import FLAGS
+    from yolov3_tensorflow_amd.utils import event_file as ef
+    saved = dict(FLAGS)
+    try:
+        rng = np.random.default_rng(0)
+        img_dir = tmp_path / 'images'
+        img_dir.mkdir()
+        lines = []
+        for i in range(6):
+            Image.fromarray(rng.integers(0, 255, (70 + 9 * i, 120 - 7 * i, 3), dtype=np.uint8)).save(img_dir / ('%d.png' % i))
+            lines.append('%d.png ' % i + ' '.join('%.2f %.2f 0.3 0.25 %d' % (0.3 + 0.1 * j, 0.4 + 0.05 * i, j % 2) for j in range(1 + i % 3)))
+        (tmp_path / 'label.txt').write_text('\n'.join(lines) + '\n')
+        FLAGS.update(train_set_dir=str(img_dir), train_label_path=str(tmp_path / 'label.txt'), test_set_dir=str(img_dir),
+                     test_label_path=str(tmp_path / 'label.txt'), input_image_size=np.array([96, 128, 3], np.int64), class_num=2,
+                     train_set_size=4, val_set_size=4, batch_size=2, epoch=2, ckpt_period=1, rectified_coord_num=3,
+                     root_path=str(tmp_path) + '/', confidence_thresh=0.2, nms_thresh=0.4, save_path=str(tmp_path / 'result'), mode='train')
+        FLAGS.step_epoch, FLAGS.step_lr = FLAGS.train_step_epoch, FLAGS.train_step_lr
+        configs.refresh_derived()
+        FLAGS.checkpoint_path = str(tmp_path / 'models' / FLAGS.type) + '/'
+        from yolov3_tensorflow_amd import run as run_mod
+        from yolov3_tensorflow_amd.dataset.file_util import FileUtil
+        from yolov3_tensorflow_amd.yolov3.trainer import YOLOv3Trainer
+        from yolov3_tensorflow_amd.yolov3.yolov3_decoder import YOLOv3Decoder
+        trainer = YOLOv3Trainer()
+        data = FileUtil.get_dataset(FLAGS.train_label_path, FLAGS.train_set_dir, image_size=FLAGS.input_image_size[0:2],
+                                    batch_size=FLAGS.batch_size, is_augment=True, is_test=False)
+        with caplog.at_level(logging.INFO):
+            trainer.train(data, None, train_steps=FLAGS.steps_per_epoch)
+        hist = trainer.history
+        assert len(hist['loss']) == 2 and all(np.isfinite(hist['loss'])) and hist['lr'] == [float(FLAGS.lr_func(0)), float(FLAGS.lr_func(1))]
+        # DetailLossLogger message (reference format)
+        detail = [r.getMessage() for r in caplog.records if 'gamma_regular_loss(' in r.getMessage()]
+        assert len(detail) == 2 and 'kernel_regular_loss(' in detail[0] and ' - head: /8:' in detail[0] and 'cls_loss' in detail[0]
+        # checkpoints: '<name>-{epoch: 3d}-{loss: .5f}.ckpt' + 'checkpoint' pointer file (reference configs.py:94, trainer.py:57-64)
+        ckdir = os.path.dirname(FLAGS.checkpoint_path)
+        files = sorted(os.listdir(ckdir))
+        assert 'checkpoint' in files and sum('.ckpt' in f for f in files) == 2, files
+        assert any('-  1- ' in f or '-  1-' in f for f in files) and any('-  2-' in f for f in files), files
+        # TensorBoard layout: main + 18 sub-loss dirs + bn_gamma, every record CRC-valid, 2 epochs each
+        tb = FLAGS.tensorboard_dir
+        subdirs = [d for d in os.listdir(tb) if os.path.isdir(os.path.join(tb, d))]
+        assert len(subdirs) == 19
+        for d in [''] + subdirs:
+            recs = ef.read_records(glob.glob(os.path.join(tb, d, 'events.out.tfevents.*'))[0])
+            assert len(recs) == (1 + 4 if d == '' else 1 + 2), (d, len(recs))
+        # a fresh trainer picks the latest checkpoint up (weights-only resume, reference trainer.py:47-67)
+        w_trained = trainer.model.g.ps.flat.clone()
+        trainer2 = YOLOv3Trainer()
+        assert torch.equal(trainer2.model.g.ps.flat, w_trained)
+        # test mode (reference run.py:41-80): GPU pipeline end to end, drawings written
+        FLAGS.mode = 'test'
+        decoder = YOLOv3Decoder(head_grid_sizes=FLAGS.head_grid_sizes, class_num=FLAGS.class_num, anchor_boxes=FLAGS.anchor_boxes)
+        os.makedirs(FLAGS.save_path, exist_ok=True)
+        results = run_mod.test(trainer2, decoder, FLAGS.save_path)
+        assert len(results) == 6 and len(os.listdir(FLAGS.save_path)) == 6
+        n_boxes = 0
+        for path, boxes in results:
+            assert len(boxes) == 3
+            for head in boxes:
+                for b in head:
+                    assert len(b) == 9 and b[7] > FLAGS.confidence_thresh and 0 <= b[6] < 2
+                    n_boxes += 1
+        assert n_boxes > 0
+    finally:
+        FLAGS.clear()
+        FLAGS.update(saved)

@@ -209,6 +209,28 @@ class YOLOv3Model(object):
             parts.append(t[..., :c].reshape(t.shape[0], H32, W32, -1))
         return torch.cat(parts, dim=-1).float().cpu().numpy()
 
+    # ---------------------------------------------------------------------------------------------- observability (per epoch)
+    def regularization_losses(self):
+        """(sum of the BN-gamma L2 terms, their count, sum of the kernel L2 terms, their count): what DetailLossLogger prints
+        (reference utils/logger_callback.py:49-58,105-108; each term is l2 * sum(w^2), basic_backbone.py:41,64,76)"""
+        ps = self.g.ps
+        sums = {'bn_gamma': 0.0, 'kernel': 0.0}
+        counts = {'bn_gamma': 0, 'kernel': 0}
+        flat = ps.flat.detach()
+        for p in ps.params.values():
+            if p.l2 > 0:
+                key = 'bn_gamma' if p.kind == 'bn_gamma' else 'kernel'
+                counts[key] += 1
+                sums[key] += p.l2 * float((flat[p.offset:p.offset + p.numel].double() ** 2).sum().item())
+        return sums['bn_gamma'], counts['bn_gamma'], sums['kernel'], counts['kernel']
+
+    def bn_gammas(self):
+        """all BatchNorm gammas concatenated (reference utils/board_callback.py:73-81) -> float32 ndarray"""
+        ps = self.g.ps
+        flat = ps.flat.detach()
+        parts = [flat[p.offset:p.offset + p.numel] for p in ps.params.values() if p.kind == 'bn_gamma']
+        return torch.cat(parts).cpu().numpy()
+
     # ---------------------------------------------------------------------------------------------- weights by Keras name
     def get_weights(self):
         """{keras variable name: float32 ndarray in TF layout (HWIO kernels)}, trainable + moving statistics"""

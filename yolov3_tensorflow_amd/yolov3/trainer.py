@@ -67,6 +67,11 @@ class YOLOv3Trainer(object):
         self.ckpt_period = FLAGS.ckpt_period
         self.stop_patience, self.stop_min_delta = FLAGS.stop_patience, FLAGS.stop_min_delta
         self.lr_func = FLAGS.lr_func
+        # callbacks (reference :89-97): checkpoint / early stopping / LR schedule are the loop below; the two custom ones are objects
+        from yolov3_tensorflow_amd.utils.logger_callback import DetailLossLogger
+        from yolov3_tensorflow_amd.utils.board_callback import MyTensorBoard
+        self.log_callback = DetailLossLogger(verbose=2)
+        self.tensorboard = MyTensorBoard(log_dir=FLAGS.tensorboard_dir)
 
     def train(self, train_set, val_set, train_steps=FLAGS.steps_per_epoch, val_steps=FLAGS.validation_steps):
         """reference :99-115.  ``train_set`` yields (images float32 (N,H,W,3) in [0,1] BGR, labels float32 (N, T*5) padded -1)."""
@@ -74,10 +79,15 @@ class YOLOv3Trainer(object):
         best, wait = np.inf, 0
         history = {'loss': [], 'lr': []}
         is_main = self.model.rank == 0
+        callbacks = [self.tensorboard, self.log_callback] if is_main else []
+        for cb in callbacks:
+            cb.set_model(self.model, self.loss_object)
+        self.log_callback.on_train_begin(self.epoch, train_steps)
         for epoch in range(self.epoch):
             lr = float(self.lr_func(epoch))                                 # LearningRateScheduler (reference :94)
             self.optimizer.lr = lr
-            t0 = time.time()
+            if is_main:
+                self.log_callback.on_epoch_begin(epoch)
             losses = []
             for _ in range(train_steps):
                 images, labels = next(it)
@@ -86,7 +96,9 @@ class YOLOv3Trainer(object):
             history['loss'].append(epoch_loss)
             history['lr'].append(lr)
             if is_main:
-                self._log_detail(epoch, lr, epoch_loss, time.time() - t0)     # DetailLossLogger (reference :95)
+                logs = {'loss': epoch_loss, 'lr': lr}
+                self.tensorboard.on_epoch_end(epoch, {'loss': epoch_loss})   # MyTensorBoard (reference :96)
+                self.log_callback.on_epoch_end(epoch, logs)                  # DetailLossLogger (reference :95)
                 if (epoch + 1) % self.ckpt_period == 0:                      # ModelCheckpoint(period) (reference :90-91)
                     path = self.checkpoint_path.format(epoch=epoch + 1, loss=epoch_loss)
                     self.model.save_weights(path)
@@ -98,14 +110,10 @@ class YOLOv3Trainer(object):
                 if wait >= self.stop_patience:
                     logging.info('early stopping at epoch %d', epoch + 1)
                     break
+        if is_main:
+            self.tensorboard.on_train_end()
         self.history = history
         logging.info('training finished')
-
-    def _log_detail(self, epoch, lr, loss, seconds):
-        lo = self.loss_object
-        logging.info('epoch %d: lr %.3g loss %.5f (%.2fs) l2 %.5f | rect %s xy %s wh %s noobj %s obj %s cls %s', epoch + 1, lr, loss, seconds,
-                     float(self.model.l2_value.item()), lo.rectified_coord_loss, lo.coord_loss_xy, lo.coord_loss_wh, lo.noobj_iou_loss,
-                     lo.obj_iou_loss, lo.class_loss)
 
     def predict(self, test_images):
         """reference :117-124"""
