@@ -45,6 +45,10 @@ def main():
     dev = torch.device('cuda:0')
     model, loss, opt, grids = bench.build_model(a.backbone, a.size, a.size, a.batch, 80, dev)
     model.overlap_wgrad = False
+    from yolov3_tensorflow_amd import ops
+    for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):
+        k, v = kv.split('=')
+        ops.set_tuning(k, int(v))
     images, labels = bench.synthetic_batch(a.batch, a.size, a.size, 80, 0)
     model.stage_batch(images, labels)
     model.run_step()

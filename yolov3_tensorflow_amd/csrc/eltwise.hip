@@ -875,6 +875,7 @@ inline int reduce_grid(int M, int C) {
 
 // ---- host side of the fused backward
 int g_fused_min_chunks = 3;
+int g_fused_small_chunks = 0;   // "bn_fused_small_grid": workgroups of the small-tensor launch; 0 = small tensors use the three-kernel path
 inline int fused_grid() {
   static int n = 0;
   if (!n) {
@@ -1024,12 +1025,15 @@ extern "C" int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu
 // yolo_bn_bwd_fused_sync_words() ints, zeroed once by the caller.  Returns 1 (and launches nothing) when the tensor does not fit the resident grid's registers: the caller
 // then uses the reduce / finalize / apply path.
 extern "C" int64_t yolo_bn_bwd_fused_workspace_floats(int C) { return C > 0 ? (int64_t)(256 * 3 + 4) * C : 0; }
-extern "C" int yolo_bn_bwd_fused_sync_words(void) { return FB_SYNC_WORDS; }
+extern "C" int yolo_bn_bwd_fused_sync_words(void) { return 2 * FB_SYNC_WORDS; }   // counters of the full grid + of the small grid
 
 extern "C" int yolo_bn_fused_timeouts(const int* sync_words, int* host_out) {
   YOLO_CHECK_ARG(sync_words && host_out, "null pointer");
-  hipError_t e = hipMemcpy(host_out, sync_words + FB_TIMEOUT_WORD, sizeof(int), hipMemcpyDeviceToHost);
+  int t[2] = {0, 0};
+  hipError_t e = hipMemcpy(&t[0], sync_words + FB_TIMEOUT_WORD, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&t[1], sync_words + FB_SYNC_WORDS + FB_TIMEOUT_WORD, sizeof(int), hipMemcpyDeviceToHost);
   if (e != hipSuccess) { yolo_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); return (int)e; }
+  *host_out = t[0] + t[1];
   return YOLO_OK;
 }
 
@@ -1041,19 +1045,29 @@ int launch_bn_bwd_fused(const void* dout, const void* out, int relu, int64_t M, 
   YOLO_CHECK_ARG(dout && y && a1 && mean && rstd && dy && workspace && sync_words && M > 0 && chan_ok(C), "bad argument");
   YOLO_CHECK_ARG(!relu || out, "relu needs out");
   YOLO_CHECK_ARG(!y2 || (a2 && mean2 && rstd2 && dy2), "second BN branch incomplete");
-  const int G = fused_grid();
-  const size_t total = (size_t)M * (C / 8), T = (size_t)G * FB_THREADS;
-  const size_t need = (total + T - 1) / T;
-  // small tensors stay on the three-kernel path: the two grid barriers cost ~20 us, more than the second read of a tensor that is
-  // L2 / Infinity-Cache resident anyway (measured: 13 x 13 and 26 x 26 maps 25 us fused vs 22 us in three launches)
-  if (need > 11 || (y2 && need > 6) || need < (size_t)g_fused_min_chunks) return 1;
+  int G = fused_grid();
+  const size_t total = (size_t)M * (C / 8);
+  size_t T = (size_t)G * FB_THREADS;
+  size_t need = (total + T - 1) / T;
+  // small tensors: with the full grid the two grid barriers cost ~20 us, more than the second read of a tensor that is L2 /
+  // Infinity-Cache resident anyway (measured: 13 x 13 and 26 x 26 maps 25 us fused vs 22 us in three launches) -- they either run
+  // on a SMALLER grid ("bn_fused_small_chunks" k > 0: as many workgroups as give every thread ~k chunks, at least 16; fewer
+  // arrivals and less launch skew per barrier) or stay on the three-kernel path
+  bool small = false;
+  if (need < (size_t)g_fused_min_chunks && g_fused_small_chunks > 0 && g_fused_small_chunks < G) {
+    // ONE small grid size for all of them: the barrier derives its generation from the counter values, so every launch that shares
+    // a set of counters must have the same grid -- the small grid has its own set (second half of sync_words)
+    G = g_fused_small_chunks; T = (size_t)G * FB_THREADS; need = (total + T - 1) / T;
+    small = true;
+  }
+  if (need > 11 || (y2 && need > 6) || (!small && need < (size_t)g_fused_min_chunks)) return 1;
   FusedBwdArgs a;
   a.dout = (const bf16_t*)dout; a.out = (const bf16_t*)out; a.relu = relu;
   a.y = (const bf16_t*)y; a.a1 = a1; a.mean = mean; a.rstd = rstd; a.grp = grp; a.dy = (bf16_t*)dy; a.acc_dy = acc_dy;
   a.y2 = (const bf16_t*)y2; a.a2 = a2; a.mean2 = mean2; a.rstd2 = rstd2; a.dgamma2 = dgamma2; a.dbeta2 = dbeta2; a.dy2 = (bf16_t*)dy2;
   a.dres = (bf16_t*)dres; a.acc_dres = acc_dres;
   a.total = total; a.C = C; a.count = (float)M;
-  a.partial = workspace; a.kbuf = workspace + (size_t)256 * 3 * C; a.sync = sync_words;
+  a.partial = workspace; a.kbuf = workspace + (size_t)256 * 3 * C; a.sync = sync_words + (small ? FB_SYNC_WORDS : 0);
   hipStream_t st = (hipStream_t)stream;
 #define YOLO_FB(MAXCH_, HAS2_) hipLaunchKernelGGL((bn_bwd_fused_kernel<MAXCH_, HAS2_>), dim3(G), dim3(FB_THREADS), 0, st, a)
   if (y2) { if (need <= 2) YOLO_FB(2, true); else YOLO_FB(6, true); }
