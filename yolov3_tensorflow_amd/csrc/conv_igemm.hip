@@ -107,6 +107,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Weight-gradient grids: logical (x = k tile, y = co tile, z = pixel split).  Every workgroup of one split reads the same pixels of X and
+// dY, so with xcd != 0 the grid is launched 1-D and each XCD gets a contiguous run of logical ids (x fastest, then y, then z): the
+// tiles of a split land on one XCD close in time and share its L2 instead of fetching the range once per XCD (PMC: the 64-channel
+// 104 x 104 weight gradient fetched 259 MB for 88 MB of operands -- one read per kernel row).
+struct Bid3 { int x, y, z; };
+__device__ __forceinline__ Bid3 wgrad_block(int gx, int gy, int xcd) {
+  if (!xcd) return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  const int l = xcd_remap(blockIdx.x, gridDim.x);
+  const int x = l % gx, t = l / gx;
+  return {x, t % gy, t / gy};
+}
+
 constexpr int BK = 64;  // K elements per stage
 
 // Tile epilogue shared by the conv kernels: lane holds channels co..co+3 (rows of D) of pixel (column of D); acc[a][b] = channel tile a x
@@ -569,7 +581,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* img, int p0, int col0, i
 }
 
 // per-stage advance of the pixel cursor (64 pixels): 64 = dn * (Ho*Wo) + dh * Wo + dw, and the byte sizes of the two streamed tensors
-struct WgradStep { int dn, dh, dw; unsigned x_bytes, y_bytes; long long slab; };   // slab > 0: split z stores to dW + z * slab (no atomics)
+struct WgradStep { int dn, dh, dw; unsigned x_bytes, y_bytes; long long slab; int gx, gy, xcd; };   // slab > 0: split z stores to dW + z * slab (no atomics)
 
 // Weight gradient dW[co][kcol] = sum over pixels dY[pix][co] * X[pix][kcol] (kcol = (tap, ci)): NW waves = 2 along co x NW/2 along
 // kcol, split-K over pixel ranges (blockIdx.z), fp32 atomics into dW.
@@ -589,9 +601,10 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(Gather g, const bf
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;  // wave tile: co [wr*BCO/2, +BCO/2) x kcol [wc*16*XT, +16*XT)
-  const int kc0 = blockIdx.x * WG_BKC, co0 = blockIdx.y * BCO;
+  const Bid3 bid = wgrad_block(ws.gx, ws.gy, ws.xcd);
+  const int kc0 = bid.x * WG_BKC, co0 = bid.y * BCO;
   const int nsteps = (g.M + WG_BP - 1) / WG_BP;
-  const int s_begin = blockIdx.z * steps_per_split;
+  const int s_begin = bid.z * steps_per_split;
   const int s_end = min(nsteps, s_begin + steps_per_split);
   if (s_begin >= s_end) return;
 
@@ -718,7 +731,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(Gather g, const bf
         for (int j = 0; j < 4; ++j) {
           const int co = co0 + wr * (BCO / 2) + a * 16 + (lane >> 4) * 4 + j;
           if (co < Kout) {
-            if (ws.slab) dW[(size_t)blockIdx.z * (size_t)ws.slab + (size_t)co * g.Kg + kc] = acc[a][b][j];
+            if (ws.slab) dW[(size_t)bid.z * (size_t)ws.slab + (size_t)co * g.Kg + kc] = acc[a][b][j];
             else         atomicAdd(dW + (size_t)co * g.Kg + kc, acc[a][b][j]);
           }
         }
@@ -748,6 +761,7 @@ struct WgradStripArgs {
   float rhw, rw;
   long long slab;             // > 0: split z stores to out + z * slab; 0: float atomics
   int steps_per_split;
+  int gx, gy, xcd;
 };
 
 __device__ __forceinline__ int wgx_f(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
@@ -760,10 +774,11 @@ __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, f
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;    // wave tile: co [wr*BCO/2, +BCO/2) x ci [wc*16, +16) x 3 taps
-  const int tr = blockIdx.x % 3, cc = blockIdx.x / 3;
-  const int co0 = blockIdx.y * BCO;
+  const Bid3 bid = wgrad_block(a.gx, a.gy, a.xcd);
+  const int tr = bid.x % 3, cc = bid.x / 3;
+  const int co0 = bid.y * BCO;
   const int nsteps = (a.M + WG_BP - 1) / WG_BP;
-  const int s_begin = blockIdx.z * a.steps_per_split;
+  const int s_begin = bid.z * a.steps_per_split;
   const int s_end = min(nsteps, s_begin + a.steps_per_split);
   if (s_begin >= s_end) return;
   char* const sZero = smem + 2 * STAGE;
@@ -895,7 +910,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, f
   }
 
   // D[row = co][col = ci]: lane holds rows 4*(lane>>4)+j, column lane&15
-  float* dst = out + (a.slab ? (size_t)blockIdx.z * (size_t)a.slab : 0);
+  float* dst = out + (a.slab ? (size_t)bid.z * (size_t)a.slab : 0);
 #pragma unroll
   for (int c = 0; c < COT; ++c)
 #pragma unroll
@@ -1036,6 +1051,7 @@ TileCfg pick_tile(int M, int Kout) {
 // strip kernel plan: 0 = not eligible, else the pixel tile BM (and the channel tile through *bnp)
 // tuning overrides (yolo_set_tuning): strip_bm = -1 auto, 0 = never use the strip kernel, 64 / 128 / 256 = force; strip_bn = 0 auto
 int g_strip_bm = -1, g_strip_bn = 0;
+int g_wgrad_xcd = 1;     // "wgrad_xcd": 1 = 1-D weight-gradient grids with one contiguous run of logical blocks per XCD, 0 = plain 3-D grid
 int g_strip_ws = 0;      // "strip_ws": 0 auto, 2 / 3 force the weight-ring depth of the strip kernel
 // workgroups aimed at by the two-phase path: 1.5 per CU measured best on the whole step (256 / 384 / 512 tried: fewer slabs to sum
 // and less competition with the main stream's kernels outweigh the shorter pixel ranges of 512)
@@ -1182,6 +1198,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "s2_classes")) { YOLO_CHECK_ARG(value == 0 || value == 1, "s2_classes"); g_s2_classes = value; }
   else if (!strcmp(name, "wgrad_target")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "wgrad_target"); g_wgrad_target = value; }
   else if (!strcmp(name, "bn_fused_small_grid")) { YOLO_CHECK_ARG(value == 0 || (value >= 16 && value <= 255), "bn_fused_small_grid"); g_fused_small_chunks = value; }
+  else if (!strcmp(name, "wgrad_xcd")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_xcd"); g_wgrad_xcd = value; }
   else if (!strcmp(name, "strip_ws")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 3, "strip_ws"); g_strip_ws = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
@@ -1294,7 +1311,8 @@ void launch_wgrad(const yolo_conv_problem* p, const WgradPlan& pl, const void* d
     a.dh = (WG_BP % hw) / p->W; a.dw = (WG_BP % hw) % p->W;
     a.d4 = 4 % p->W; a.d32 = 32 % p->W; a.d36 = 36 % p->W;
     a.rhw = g.rhw; a.rw = g.rw; a.slab = slab; a.steps_per_split = pl.sps;
-    const dim3 grid(pl.tiles_k, pl.tiles_c, pl.split_k);
+    a.gx = pl.tiles_k; a.gy = pl.tiles_c; a.xcd = g_wgrad_xcd;
+    const dim3 grid = g_wgrad_xcd ? dim3(pl.tiles_k * pl.tiles_c * pl.split_k) : dim3(pl.tiles_k, pl.tiles_c, pl.split_k);
     const size_t lds = 2 * (72 * 128 + WG_BP * 256) + 128;
     if (pl.bco == 128) hipLaunchKernelGGL(wgrad3x3_strip_kernel<128>, grid, dim3(512), lds, stream, a, out);
     else               hipLaunchKernelGGL(wgrad3x3_strip_kernel<64>, grid, dim3(512), lds, stream, a, out);
@@ -1312,7 +1330,8 @@ void launch_wgrad(const yolo_conv_problem* p, const WgradPlan& pl, const void* d
   const bool cat = p->C0 > 0 || xb >= (1ull << 31) || yb >= (1ull << 31) || (size_t)p->N * p->H * p->W >= (1u << 24);
   ws.x_bytes = cat ? 0u : (unsigned)xb;
   ws.y_bytes = cat ? 0u : (unsigned)yb;
-  const dim3 grid(pl.tiles_k, pl.tiles_c, pl.split_k);
+  ws.gx = pl.tiles_k; ws.gy = pl.tiles_c; ws.xcd = g_wgrad_xcd;
+  const dim3 grid = g_wgrad_xcd ? dim3(pl.tiles_k * pl.tiles_c * pl.split_k) : dim3(pl.tiles_k, pl.tiles_c, pl.split_k);
 #define YOLO_WGRAD_LAUNCH(BCO_, CAT_)                                                                                          \
   hipLaunchKernelGGL((igemm_wgrad_kernel<BCO_, 8, CAT_>), grid, dim3(512), lds, stream, g, (const bf16_t*)dy, p->Cout, out, p->Cout, \
                      pl.sps, ws)
