@@ -155,6 +155,8 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay two hipGraphs instead of eager two-stream launches (measured slower: the '
                     'forked weight-gradient branch is serialised under replay)')
     ap.add_argument('--no-overlap', action='store_true', help='weight-gradient GEMMs on the main stream')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'], help='16-bit compute type: bf16 (default) or fp16 (libyolov3_amd_fp16.so + '
+                    'static loss scaling; BASELINE.json configs[4])')
     ap.add_argument('--focal', action='store_true', help='focal loss on (BASELINE.json configs[4])')
     ap.add_argument('--no-fused-bn', action='store_true', help='three-kernel BatchNorm backward instead of the single-launch one')
     args = ap.parse_args()
@@ -165,6 +167,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    from yolov3_tensorflow_amd import backend
+    backend.set_compute_dtype(args.dtype)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda:%d' % local_rank)
     if world > 1:
@@ -213,9 +217,9 @@ def main():
     ips = args.batch * world * args.steps / elapsed
     gflop = TRAIN_GFLOP_PER_IMAGE if (args.size == 416 and args.classes == 80 and args.backbone == 'resnet-18') else None
     out = {
-        'metric': 'images/sec training 416x416 ResNet18-YOLOv3 (bf16)',
+        'metric': 'images/sec training 416x416 ResNet18-YOLOv3 (%s)' % args.dtype,
         'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+        'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
         'data': 'synthetic',
         'config': {'workload': '%s-YOLOv3 %dx%d, %d classes, anchors 3/3/3 (COCO-9), per-GPU batch %d, full training step '
                                '(fwd + YOLOv3 %sloss + bwd + RAdam/L2%s), random-init weights'

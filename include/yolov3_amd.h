@@ -26,8 +26,13 @@ extern "C" {
 #define YOLO_OK 0
 #define YOLO_ERR_INVALID_ARG (-1)
 #define YOLO_ABI_VERSION 1
+#define YOLO_DTYPE_BF16 0
+#define YOLO_DTYPE_FP16 1
 
 int yolo_abi_version(void);
+/* 16-bit element type of this build: YOLO_DTYPE_BF16 (libyolov3_amd.so) or YOLO_DTYPE_FP16 (libyolov3_amd_fp16.so, the same sources
+ * compiled with -DYOLO_FP16: wherever this header says "bf16" that library stores IEEE half and multiplies with the f16 MFMA). */
+int yolo_abi_dtype(void);
 const char* yolo_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -199,6 +204,8 @@ typedef struct {
   float focal_alpha, focal_gamma;
   int32_t is_tiou_recall;
   float eps;                         /* K.epsilon() = 1e-8 (run.py:26) */
+  float grad_scale16;                /* factor on the 16-bit d(logits) copies only (static loss scaling for fp16 training; the float32
+                                        d(logits), the loss terms and the total are never scaled); 0 is read as 1 */
 } yolo_loss_config;
 
 int64_t yolo_loss_workspace_bytes(const yolo_loss_config* c, int N);

@@ -21,7 +21,8 @@ class OracleTrainer(object):
         self.loss = YOLOv3LossOracle(head_grid_sizes, class_num, anchor_boxes, iou_thresh, loss_weights, rectified_coord_num,
                                      rectified_loss_weight, is_focal_loss, focal_alpha, focal_gamma, is_tiou_recall)
         self.opt = RAdamOracle(lr=lr, scalar_dtype=scalar_dtype)
-        self.round_fn = bf16_round if emulate_bf16 else None
+        # emulate_bf16: False, True (bfloat16 storage points) or 'float16' (the product's fp16 build)
+        self.round_fn = (lambda x: x.to(torch.float16).to(x.dtype)) if emulate_bf16 == 'float16' else (bf16_round if emulate_bf16 else None)
         self.round_grads = bool(emulate_bf16_grads and emulate_bf16)
         self.box_num = [len(a) for a in anchor_boxes]
         self.L = L

@@ -21,14 +21,19 @@ def test_header_declares_functions():
     assert len(names) >= 25
 
 
-def test_library_exports_every_declared_symbol():
+@pytest.mark.parametrize('which', ['bfloat16', 'float16'])
+def test_library_exports_every_declared_symbol(which):
+    """both builds of the sources (bf16 default, -DYOLO_FP16) export the whole C-ABI and report their element type"""
     from yolov3_tensorflow_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        pytest.fail('libyolov3_amd.so is not built (run __graft_entry__.build())')
-    lib = ctypes.CDLL(_lib.LIB_PATH)
+    path = _lib.LIB_PATH_FP16 if which == 'float16' else _lib.LIB_PATH
+    if not os.path.exists(path):
+        pytest.fail('%s is not built (run __graft_entry__.build())' % os.path.basename(path))
+    lib = ctypes.CDLL(path)
     for name in declared_functions():
         assert hasattr(lib, name), 'missing export ' + name
     assert lib.yolo_abi_version() == 1
+    assert lib.yolo_abi_dtype() == (1 if which == 'float16' else 0)
+    assert _lib.load(which).yolo_abi_dtype() == (1 if which == 'float16' else 0)
 
 
 def test_ctypes_table_matches_header():
@@ -52,10 +57,13 @@ def test_argument_validation_without_gpu():
 
 def test_missing_library_fails_loudly(monkeypatch):
     from yolov3_tensorflow_amd import _lib
-    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, '_libs', {})
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libyolov3_amd.so')
+    monkeypatch.setattr(_lib, 'LIB_PATH_FP16', '/nonexistent/libyolov3_amd_fp16.so')
     with pytest.raises(_lib.YoloNativeError):
         _lib.load()
+    with pytest.raises(_lib.YoloNativeError):
+        _lib.load('float16')
 
 
 def test_kernel_plans_are_consistent_without_gpu():

@@ -21,8 +21,22 @@ def dev():
     return torch.device('cuda:0')
 
 
+def ACT():
+    """the 16-bit element type of the library in use (bfloat16, or float16 under the fp16 fixture)"""
+    from yolov3_tensorflow_amd import backend
+    return backend.torch_dtype()
+
+
 def bf(x):
-    return x.to(torch.bfloat16)
+    return x.to(ACT())
+
+
+@pytest.fixture
+def fp16():
+    from yolov3_tensorflow_amd import backend
+    backend.set_compute_dtype('float16')
+    yield
+    backend.set_compute_dtype('bfloat16')
 
 
 def ref_conv(x, w_hwio, stride, pt, pl, Ho, Wo):
@@ -76,7 +90,7 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
 
     xd = x.to(dev)
     w_fwd = w.permute(3, 0, 1, 2).contiguous().to(dev)          # [Cout][R][S][Cin]
-    y = torch.empty(N, Ho, Wo, Cout, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(N, Ho, Wo, Cout, dtype=ACT(), device=dev)
     rows = ops.conv2d_stat_rows(p)
     ssum = torch.zeros(rows, Cout, device=dev)
     ssq = torch.zeros(rows, Cout, device=dev)
@@ -119,11 +133,11 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert torch.equal(dw3, dw4), 'two-phase weight gradient must be run-to-run deterministic'
 
     if Cin % 64 == 0:
-        w_dg = torch.empty(Cin, k, k, Cout, dtype=torch.bfloat16, device=dev)
+        w_dg = torch.empty(Cin, k, k, Cout, dtype=ACT(), device=dev)
         ops.repack_dgrad_weights(w_fwd, w_dg, Cout, k, k, Cin)
         ref_dg = w.permute(2, 0, 1, 3).flip(1, 2).contiguous()
         assert torch.equal(w_dg.cpu(), ref_dg)
-        dx = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
+        dx = torch.empty(N, H, W, Cin, dtype=ACT(), device=dev)
         ops.conv2d_dgrad(p, dyd, w_dg, dx)
         torch.testing.assert_close(dx.float().cpu(), xr.grad, rtol=1e-2, atol=1e-2)
         ops.conv2d_dgrad(p, dyd, w_dg, dx, accumulate=True)        # fan-in accumulation: dx += dgrad
@@ -142,15 +156,15 @@ def test_strip_conv_variants_match_implicit_gemm(dev, bm, bn):
     w = bf(torch.randn(Cout, 3, 3, Cin, generator=g) * 0.03).to(dev)
     dy = bf(torch.randn(N, H, W, Cout, generator=g)).to(dev)
     p = ops.conv_problem(N, H, W, Cin, Cout, 3, 1, 'same')
-    w_dg = torch.empty(Cin, 3, 3, Cout, dtype=torch.bfloat16, device=dev)
+    w_dg = torch.empty(Cin, 3, 3, Cout, dtype=ACT(), device=dev)
     ops.repack_dgrad_weights(w, w_dg, Cout, 3, 3, Cin)
 
     def run():
         rows = ops.conv2d_stat_rows(p)
-        y = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(N, H, W, Cout, dtype=ACT(), device=dev)
         ss, sq = torch.zeros(rows, Cout, device=dev), torch.zeros(rows, Cout, device=dev)
         ops.conv2d_fwd(p, x, w, y, stat_sum=ss, stat_sq=sq)
-        dx = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
+        dx = torch.empty(N, H, W, Cin, dtype=ACT(), device=dev)
         ops.conv2d_dgrad(p, dy, w_dg, dx)
         ops.conv2d_dgrad(p, dy, w_dg, dx, accumulate=True)
         torch.cuda.synchronize()
@@ -217,11 +231,11 @@ def test_stride2_dgrad_parity_classes_match_strided_gather(dev, shape):
     w = bf(torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).to(dev)
     dy = bf(torch.randn(N, p.Ho, p.Wo, Cout, generator=g)).to(dev)
     base = bf(torch.randn(N, H, W, Cin, generator=g)).to(dev)
-    w_dg = torch.empty(Cin, 3, 3, Cout, dtype=torch.bfloat16, device=dev)
+    w_dg = torch.empty(Cin, 3, 3, Cout, dtype=ACT(), device=dev)
     ops.repack_dgrad_weights(w, w_dg, Cout, 3, 3, Cin)
 
     def run():
-        dx = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=dev)
+        dx = torch.empty(N, H, W, Cin, dtype=ACT(), device=dev)
         ops.conv2d_dgrad(p, dy, w_dg, dx)
         acc = base.clone()
         ops.conv2d_dgrad(p, dy, w_dg, acc, accumulate=True)
@@ -254,7 +268,7 @@ def test_conv_fused_upsample_concat(dev):
     y_ref.backward(dy.float())
     p = ops.conv_problem(N, H, W, C0 + C1, Cout, 1, 1, 'same', C0=C0)
     w_fwd = w.permute(3, 0, 1, 2).contiguous().to(dev)
-    y = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(N, H, W, Cout, dtype=ACT(), device=dev)
     ops.conv2d_fwd(p, b.to(dev), w_fwd, y, src0=a.to(dev))
     torch.testing.assert_close(y.float().cpu(), y_ref.detach(), rtol=1e-2, atol=1e-2)
     dw = torch.zeros(Cout, 1, 1, C0 + C1, device=dev)
@@ -266,12 +280,12 @@ def test_conv_fused_upsample_concat(dev):
     torch.testing.assert_close(dw_r.cpu(), wr.grad.permute(3, 0, 1, 2), rtol=1e-3, atol=1e-3)
     # dgrad over the virtual concat, then the split kernel
     pd = ops.conv_problem(N, H, W, C0 + C1, Cout, 1, 1, 'same')
-    w_dg = torch.empty(C0 + C1, 1, 1, Cout, dtype=torch.bfloat16, device=dev)
+    w_dg = torch.empty(C0 + C1, 1, 1, Cout, dtype=ACT(), device=dev)
     ops.repack_dgrad_weights(w_fwd, w_dg, Cout, 1, 1, C0 + C1)
-    dcat = torch.empty(N, H, W, C0 + C1, dtype=torch.bfloat16, device=dev)
+    dcat = torch.empty(N, H, W, C0 + C1, dtype=ACT(), device=dev)
     ops.conv2d_dgrad(pd, dy.to(dev), w_dg, dcat)
-    da = torch.empty(N, H // 2, W // 2, C0, dtype=torch.bfloat16, device=dev)
-    db = torch.full((N, H, W, C1), 1.0, dtype=torch.bfloat16, device=dev)
+    da = torch.empty(N, H // 2, W // 2, C0, dtype=ACT(), device=dev)
+    db = torch.full((N, H, W, C1), 1.0, dtype=ACT(), device=dev)
     ops.upcat_split_bwd(dcat, da, False, db, True, N, H, W, C0, C1)
     gcat = cat.grad
     da_ref = gcat[..., :C0].reshape(N, H // 2, 2, W // 2, 2, C0).sum(dim=(2, 4))
@@ -331,7 +345,7 @@ def test_bn_act_fwd_bwd(dev, mode):
     torch.testing.assert_close(rstd.cpu(), torch.rsqrt(v1.detach() + 1e-5), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(mm.cpu(), 0.1 * m1.detach(), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(mv.cpu(), 0.9 + 0.1 * v1.detach() * M / (M - 1), rtol=1e-4, atol=1e-5)
-    out = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(N, H, W, Cc, dtype=ACT(), device=dev)
     kw = {}
     if mode == 'res':
         kw = dict(res=y2d)
@@ -354,7 +368,7 @@ def test_bn_act_fwd_bwd(dev, mode):
     ops.bn_bwd_finalize(partial, P, Cc, 1, M, dga, dbe, k1, k2)
     torch.testing.assert_close(dga.cpu(), gr.grad, rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(dbe.cpu(), br.grad, rtol=2e-3, atol=2e-3)
-    dy = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=dev)
+    dy = torch.empty(N, H, W, Cc, dtype=ACT(), device=dev)
     if mode == 'plain':
         ops.bn_act_bwd_apply(dout_d, out_d, True, M, Cc, y=yd, a1=sc, mean=mean, rstd=rstd, k1=k1, k2=k2, dy=dy)
     elif mode == 'res':
@@ -471,7 +485,7 @@ def test_bn_pool_relu_fwd_bwd(dev):
     ops.bn_stats(yd, M, Cc, part)
     sc, sh, mean, rstd = [torch.empty(Cc, device=dev) for _ in range(4)]
     ops.bn_finalize(part, part[0, 1], rows, 2 * Cc, Cc, M, d(gamma), d(beta), 1e-5, 0.9, None, None, sc, sh, mean, rstd)
-    out = torch.empty(N, Ho, Wo, Cc, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(N, Ho, Wo, Cc, dtype=ACT(), device=dev)
     arg = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=dev)
     ops.bn_pool_fwd(yd, sc, sh, out, arg, N, H, W, Cc, Ho, Wo, pt, pl, True)
     torch.testing.assert_close(out.float().cpu(), out_b.float(), rtol=1e-2, atol=1e-2)
@@ -483,7 +497,7 @@ def test_bn_pool_relu_fwd_bwd(dev):
         ops.bn_bwd_finalize(partial, rows, Cc, 1, M, dga, dbe, k1, k2)
         torch.testing.assert_close(dga.cpu(), gr.grad, rtol=1e-2, atol=2e-2)
         torch.testing.assert_close(dbe.cpu(), br.grad, rtol=5e-3, atol=5e-3)
-    dy = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=dev)
+    dy = torch.empty(N, H, W, Cc, dtype=ACT(), device=dev)
     ops.bn_pool_bwd_apply(d(dout), out, arg, True, yd, sc, mean, rstd, k1, k2, dy, N, H, W, Cc, Ho, Wo, pt, pl)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-2)
 
@@ -510,11 +524,11 @@ def test_mixconv_fwd_dgrad_wgrad(dev, f, N, H, W):
     y_ref.backward(dy.float())
     p = ops.mix_problem(N, H, W, f, split, ks)
     d = lambda t: t.to(dev)
-    y = torch.empty(N, H, W, f, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(N, H, W, f, dtype=ACT(), device=dev)
     wd = [d(w) for w in ws]
     ops.dwconv_mix_fwd(p, d(x), wd, y)
     torch.testing.assert_close(y.float().cpu(), y_ref.detach(), rtol=1e-2, atol=1e-2)
-    dx = torch.full((N, H, W, f), 0.5, dtype=torch.bfloat16, device=dev)
+    dx = torch.full((N, H, W, f), 0.5, dtype=ACT(), device=dev)
     ops.dwconv_mix_dgrad(p, d(dy), wd, dx, accumulate=True)
     torch.testing.assert_close(dx.float().cpu(), xr.grad + 0.5, rtol=1e-2, atol=2e-2)
     dw = [torch.full((k, k, split[i + 1] - split[i]), 3.0, device=dev) for i, k in enumerate(ks)]
@@ -530,7 +544,7 @@ def test_mixconv_fwd_dgrad_wgrad(dev, f, N, H, W):
 def test_pack_input(dev):
     from yolov3_tensorflow_amd import ops
     img = torch.rand(2, 6, 5, 3)
-    out = torch.empty(2, 6, 5, 8, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(2, 6, 5, 8, dtype=ACT(), device=dev)
     ops.pack_input(img.to(dev), out, 2 * 6 * 5, 3)
     ref = torch.zeros(2, 6, 5, 8)
     ref[..., :3] = img
@@ -597,7 +611,7 @@ def test_loss_fwd_bwd_vs_oracle(dev, case):
         t[..., :B[h] * L] = raw[h].reshape(N, gh, gw, B[h] * L)
         logits.append(t.to(dev))
         dl.append(torch.zeros(N, gh, gw, ldc[h], device=dev))
-        dlb.append(torch.zeros(N, gh, gw, ldc[h], dtype=torch.bfloat16, device=dev))
+        dlb.append(torch.zeros(N, gh, gw, ldc[h], dtype=ACT(), device=dev))
     ws = torch.empty(ops.loss_workspace_bytes(cfg, N), dtype=torch.uint8, device=dev)
     cur = torch.zeros(1, dtype=torch.int32, device=dev)
     terms = torch.empty(6, 3, device=dev)
@@ -633,7 +647,7 @@ def test_loss_fwd_bwd_vs_oracle(dev, case):
         assert torch.count_nonzero(got[..., B[h] * L:]) == 0
         denom = gref.abs().max().item()
         torch.testing.assert_close(got[..., :B[h] * L], gref, rtol=1e-3, atol=1e-5 * max(denom, 1.0))
-        torch.testing.assert_close(dlb[h].float().cpu(), got.to(torch.bfloat16).float(), rtol=0, atol=0)
+        torch.testing.assert_close(dlb[h].float().cpu(), got.to(ACT()).float(), rtol=0, atol=0)
     # second call: counter advanced -> rectified term switches off when current_num > rectified_coord_num
     ops.loss_fwd_bwd(cfg, N, N, logits, lab.to(dev), cur, terms, total, ws, dlogits=dl)
     total2 = orc.loss_heads(lab.reshape(N, -1), [r.clone() for r in raw])
@@ -657,7 +671,7 @@ def test_radam_l2_step_vs_oracle(dev):
     pr = p0.copy()
     d = lambda a: torch.from_numpy(a).to(dev)
     p, m, v = d(p0.copy()), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-    pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    pb = torch.empty(n, dtype=ACT(), device=dev)
     sched = torch.tensor([1e-3, 0, 0, 0], device=dev)
     it = torch.zeros(1, dtype=torch.int64, device=dev)
     l2p = torch.empty(ops.radam_l2_blocks(n), device=dev)
@@ -679,4 +693,23 @@ def test_radam_l2_step_vs_oracle(dev):
         np.testing.assert_allclose(p.cpu().numpy(), pr, rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(l2out.cpu().numpy()[0], l2_ref, rtol=1e-5)
         assert torch.count_nonzero(gd) == 0
-        assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
+        assert torch.equal(pb.cpu(), p.cpu().to(ACT()))
+
+
+# ---- the fp16 build (libyolov3_amd_fp16.so: same sources, IEEE half elements, f16 MFMA) through the same checks ----
+FP16_CONV = [CONV_CASES[i] for i in (0, 1, 2, len(CONV_CASES) - 5, len(CONV_CASES) - 4, len(CONV_CASES) - 2, len(CONV_CASES) - 1)]
+
+
+@pytest.mark.parametrize('case', FP16_CONV, ids=[str(c) for c in FP16_CONV])
+def test_fp16_build_conv_fwd_dgrad_wgrad(dev, fp16, case):
+    from yolov3_tensorflow_amd import _lib
+    assert _lib.load().yolo_abi_dtype() == 1
+    test_conv_fwd_dgrad_wgrad(dev, case)
+
+
+def test_fp16_build_strip_and_wgrad_strip(dev, fp16):
+    test_strip_conv_variants_match_implicit_gemm(dev, 128, 64)
+    test_wgrad_strip_matches_generic(dev, (3, 21, 19, 128, 256))
+    test_bn_act_fwd_bwd(dev, 'res_bn')
+    test_bn_pool_relu_fwd_bwd(dev)
+    test_mixconv_fwd_dgrad_wgrad(dev, 128, 2, 11, 9)

@@ -49,11 +49,27 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
 
 
-@pytest.mark.parametrize('backbone,rect', [('resnet-18', -1), ('resnet-18', 1464), ('resnet-18-v2', -1), ('mixnet-18', -1)])
-def test_forward_loss_grads_and_step(backbone, rect):
+@pytest.fixture
+def compute_dtype(request):
+    """build the model in the requested 16-bit type (float16 = libyolov3_amd_fp16.so + static loss scaling), restore bfloat16 after"""
+    from yolov3_tensorflow_amd import backend
+    backend.set_compute_dtype(request.param)
+    yield request.param
+    backend.set_compute_dtype('bfloat16')
+
+
+@pytest.mark.parametrize('backbone,rect,compute_dtype', [('resnet-18', -1, 'bfloat16'), ('resnet-18', 1464, 'bfloat16'),
+                                                         ('resnet-18-v2', -1, 'bfloat16'), ('mixnet-18', -1, 'bfloat16'),
+                                                         ('resnet-18-v2', -1, 'float16'), ('resnet-18', 1464, 'float16'),
+                                                         ('mixnet-18', -1, 'float16')], indirect=['compute_dtype'])
+def test_forward_loss_grads_and_step(backbone, rect, compute_dtype):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from oracle.train import OracleTrainer
+    from yolov3_tensorflow_amd import backend
+    half = compute_dtype == 'float16'
+    S = backend.loss_scale()
+    assert S == (1024.0 if half else 1.0)
     # sized so that every BatchNorm sees >= 200 samples (N*H*W at the /32 stage): with 96x96 inputs and batch 2 the /32
     # BatchNorms normalise over 18 samples and the gradients become so ill-conditioned that the oracle's own float32 and
     # bf16-forward gradients differ by 50 % -- nothing can be checked there
@@ -65,7 +81,7 @@ def test_forward_loss_grads_and_step(backbone, rect):
     model.use_hip_graph = False
 
     orc = {}
-    for tag, emu, emug in (('f32', False, False), ('bf16', True, False)):
+    for tag, emu, emug in (('f32', False, False), ('bf16', 'float16' if half else True, False)):
         o = OracleTrainer(backbone, grids, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=rect, rectified_loss_weight=[1.0, 1.0, 1.0],
                           emulate_bf16=emu, emulate_bf16_grads=emug)
         o.ensure_params(images)
@@ -80,7 +96,8 @@ def test_forward_loss_grads_and_step(backbone, rect):
     torch.cuda.synchronize()
     heads_gpu = [h.buf[..., :c].float().cpu() for h, c in zip(model.heads, model.head_channel_nums)]
     loss_gpu = float(loss.total.item())
-    grad_flat = model.g.ps.grad.detach().cpu()
+    grad_flat = model.g.ps.grad.detach().cpu() / S          # the backward pass runs on loss-scaled 16-bit gradients (fp16 build)
+    assert model.heads[0].dy.dtype == (torch.float16 if half else torch.bfloat16)
 
     res = {}
     for tag, o in orc.items():
@@ -123,7 +140,7 @@ def test_forward_loss_grads_and_step(backbone, rect):
     for _, t in oi.det.params.trainable():
         t.grad = None
     oi.loss.current_num = 0
-    heads_i, yolo_i, _ = oi.forward_loss(images, labels, inject=[torch.as_tensor(images).to(torch.bfloat16).float()] + inject)
+    heads_i, yolo_i, _ = oi.forward_loss(images, labels, inject=[torch.as_tensor(images).to(backend.torch_dtype()).float()] + inject)
     yolo_i.backward()
     assert abs(loss_gpu - float(yolo_i.item())) <= 1e-4 * abs(loss_gpu)
     errs = []

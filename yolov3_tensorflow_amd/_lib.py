@@ -7,6 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libyolov3_amd.so')
+LIB_PATH_FP16 = os.path.join(_HERE, 'libyolov3_amd_fp16.so')
 
 MAX_ANCHORS = 8
 
@@ -27,7 +28,8 @@ class LossConfig(C.Structure):
                 ('w_xy', C.c_float * 3), ('w_wh', C.c_float * 3), ('w_noobj', C.c_float * 3), ('w_obj', C.c_float * 3),
                 ('w_cls', C.c_float * 3), ('w_rect', C.c_float * 3),
                 ('rectified_coord_num', C.c_int32), ('is_focal_loss', C.c_int32),
-                ('focal_alpha', C.c_float), ('focal_gamma', C.c_float), ('is_tiou_recall', C.c_int32), ('eps', C.c_float)]
+                ('focal_alpha', C.c_float), ('focal_gamma', C.c_float), ('is_tiou_recall', C.c_int32), ('eps', C.c_float),
+                ('grad_scale16', C.c_float)]
 
 
 class ImageDesc(C.Structure):
@@ -45,6 +47,7 @@ LP = C.POINTER(LossConfig)
 # name -> (restype, argtypes); must list every function declared in include/yolov3_amd.h
 SIGNATURES = {
     'yolo_abi_version': (I, []),
+    'yolo_abi_dtype': (I, []),
     'yolo_last_error': (C.c_char_p, []),
     'yolo_conv2d_stat_rows': (I, [CP]),
     'yolo_set_tuning': (I, [C.c_char_p, I]),
@@ -95,29 +98,34 @@ SIGNATURES = {
     'yolo_sum_partials': (I, [P, I, P, P, P]),
 }
 
-_lib = None
+_libs = {}
 
 
 class YoloNativeError(RuntimeError):
     pass
 
 
-def load():
-    """Load libyolov3_amd.so (once).  Raises if it has not been built: there is no CPU fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(dtype=None):
+    """Load the library of the current compute dtype (backend.compute_dtype(); once each).  Raises if it has not been built: there
+    is no CPU fallback."""
+    if dtype is None:
+        from yolov3_tensorflow_amd import backend
+        dtype = backend.compute_dtype()
+    lib = _libs.get(dtype)
+    if lib is not None:
+        return lib
+    path = LIB_PATH_FP16 if dtype == 'float16' else LIB_PATH
+    if not os.path.exists(path):
         raise YoloNativeError('%s not found: build it with `make -C %s` (or __graft_entry__.build()); the MI355X path has no '
-                              'fallback' % (LIB_PATH, os.path.join(_HERE, 'csrc')))
-    lib = C.CDLL(LIB_PATH)
+                              'fallback' % (path, os.path.join(_HERE, 'csrc')))
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.yolo_abi_version() != 1:
-        raise YoloNativeError('ABI version mismatch')
-    _lib = lib
+    if lib.yolo_abi_version() != 1 or lib.yolo_abi_dtype() != (1 if dtype == 'float16' else 0):
+        raise YoloNativeError('ABI version / dtype mismatch in ' + path)
+    _libs[dtype] = lib
     return lib
 
 

@@ -14,3 +14,10 @@ void yolo_set_error(const char* fmt, ...) {
 
 extern "C" int yolo_abi_version(void) { return YOLO_ABI_VERSION; }
 extern "C" const char* yolo_last_error(void) { return g_err; }
+extern "C" int yolo_abi_dtype(void) {
+#ifdef YOLO_FP16
+  return YOLO_DTYPE_FP16;
+#else
+  return YOLO_DTYPE_BF16;
+#endif
+}

@@ -4,9 +4,16 @@
 #include <stdint.h>
 #include "../../include/yolov3_amd.h"
 
-typedef uint16_t bf16_t;  // storage type of a bfloat16 element
+// The 16-bit activation / compute-copy element.  Default build: bfloat16.  -DYOLO_FP16 (libyolov3_amd_fp16.so): IEEE half -- same
+// kernels, same layouts; only the conversions below and the MFMA opcode differ.  The names keep "bf16" in both builds.
+typedef uint16_t bf16_t;  // storage type of one element
+#ifdef YOLO_FP16
+typedef _Float16 bf16x8_t __attribute__((ext_vector_type(8)));
+#define YOLO_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#else
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#define YOLO_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -30,18 +37,30 @@ void yolo_set_error(const char* fmt, ...);
     }                                                                                    \
   } while (0)
 
-// ---- bf16 <-> f32 (round-to-nearest-even; hipcc lowers the cast to v_cvt_pk_bf16_f32 on gfx950) ----
+// ---- 16-bit element <-> f32 (round-to-nearest-even; bf16: v_cvt_pk_bf16_f32, fp16: v_cvt_f16_f32 / v_cvt_f32_f16) ----
+#ifdef YOLO_FP16
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  _Float16 h = (_Float16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float lo2f(uint32_t w) { return bf2f((bf16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float hi2f(uint32_t w) { return bf2f((bf16_t)(w >> 16)); }
+#else
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
+__device__ __forceinline__ float lo2f(uint32_t w) { return __uint_as_float(w << 16); }          // element in the low / high half of a dword
+__device__ __forceinline__ float hi2f(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
 __device__ __forceinline__ void unpack_bf8(const uint4& v, float* f) {
-  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  f[0] = lo2f(v.x); f[1] = hi2f(v.x);
+  f[2] = lo2f(v.y); f[3] = hi2f(v.y);
+  f[4] = lo2f(v.z); f[5] = hi2f(v.z);
+  f[6] = lo2f(v.w); f[7] = hi2f(v.w);
 }
 __device__ __forceinline__ uint4 pack_bf8(const float* f) {
   uint4 v;

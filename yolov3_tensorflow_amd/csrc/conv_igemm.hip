@@ -171,8 +171,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
         o.y = pack_bf2(acc[a][b][2], acc[a][b][3]);
         *reinterpret_cast<uint2*>(smem + pl * OLD + cl * 2) = o;
         if (stat_sum && !accumulate && m0 + pl < M) {   // statistics of the values as stored (bf16-rounded)
-          const float r0 = __uint_as_float(o.x << 16), r1 = __uint_as_float(o.x & 0xffff0000u);
-          const float r2 = __uint_as_float(o.y << 16), r3 = __uint_as_float(o.y & 0xffff0000u);
+          const float r0 = lo2f(o.x), r1 = hi2f(o.x);
+          const float r2 = lo2f(o.y), r3 = hi2f(o.y);
           ssum[a][0] += r0; ssum[a][1] += r1; ssum[a][2] += r2; ssum[a][3] += r3;
           ssq[a][0] += r0 * r0; ssq[a][1] += r1 * r1; ssq[a][2] += r2 * r2; ssq[a][3] += r3 * r3;
         }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16
 #pragma unroll
       for (int a = 0; a < CT; ++a)
 #pragma unroll
-        for (int b = 0; b < PT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < PT; ++b) acc[a][b] = YOLO_MFMA_16x16x32(wf[a], pf[b], acc[a][b]);
     }
   };
 
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, con
 #pragma unroll
       for (int a_ = 0; a_ < CT; ++a_)
 #pragma unroll
-        for (int b = 0; b < PT; ++b) acc[a_][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a_], pf[b], acc[a_][b], 0, 0, 0);
+        for (int b = 0; b < PT; ++b) acc[a_][b] = YOLO_MFMA_16x16x32(wf[a_], pf[b], acc[a_][b]);
     }
   };
 
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(Gather g, const bf
 #pragma unroll
       for (int a = 0; a < COT; ++a)
 #pragma unroll
-        for (int b = 0; b < XT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < XT; ++b) acc[a][b] = YOLO_MFMA_16x16x32(yf[a], xf[b], acc[a][b]);
     }
   };
 
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, f
 #pragma unroll
       for (int c = 0; c < COT; ++c)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) acc[c][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[c], xf[s], acc[c][s], 0, 0, 0);
+        for (int s = 0; s < 3; ++s) acc[c][s] = YOLO_MFMA_16x16x32(yf[c], xf[s], acc[c][s]);
     }
     // advance the lane's pixel cursor by 64
     x0 += a.dw;

@@ -293,8 +293,9 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
       if (dg) *reinterpret_cast<float4*>(dg + off) = make_float4(v[0], v[1], v[2], v[3]);
       if (eg) {
         uint2 o;
-        o.x = pack_bf2(v[0], v[1]);
-        o.y = pack_bf2(v[2], v[3]);
+        const float gs16 = c.grad_scale16;            // loss scaling of the 16-bit gradient copy that feeds the backward pass
+        o.x = pack_bf2(v[0] * gs16, v[1] * gs16);
+        o.y = pack_bf2(v[2] * gs16, v[3] * gs16);
         *reinterpret_cast<uint2*>(eg + off) = o;
       }
     }
@@ -414,6 +415,7 @@ extern "C" int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_glo
   YOLO_CHECK_ARG(c->T > 0 && c->T <= 512 && c->L >= 5 && c->L <= 4096, "bad T / L");
   LossCfg cfg;
   cfg.c = *c;
+  if (cfg.c.grad_scale16 == 0.f) cfg.c.grad_scale16 = 1.f;
   int max_ldc = 0;
   for (int h = 0; h < 3; ++h) {
     YOLO_CHECK_ARG(c->H[h] > 0 && c->W[h] > 0 && c->B[h] > 0 && c->B[h] <= YOLO_MAX_ANCHORS, "bad head geometry");

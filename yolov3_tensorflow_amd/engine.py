@@ -14,7 +14,7 @@ import collections
 import math
 import numpy as np
 import torch
-from . import ops
+from . import ops, backend
 
 L2_CONV_DECAY = 5e-4       # reference backbone/basic_backbone.py:11
 BN_L2_GAMMA_DECAY = 1e-5   # :12
@@ -79,7 +79,7 @@ class ParamStore(object):
         self.grad = torch.zeros(n, device=device)
         self.m = torch.zeros(n, device=device)
         self.v = torch.zeros(n, device=device)
-        self.bf16 = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        self.bf16 = torch.zeros(n, dtype=backend.torch_dtype(), device=device)
         self.l2_table = l2.to(device)
         ops.cast_f32_to_bf16(self.flat, self.bf16, n)
 
@@ -196,7 +196,7 @@ class Graph(object):
         self.bucket_cut, self.bucket_offset, self.on_bucket = -1, 0, None
 
     # ------------------------------------------------------------------------------------------------ allocation helpers
-    def _buffer(self, shape, dtype=torch.bfloat16):
+    def _buffer(self, shape, dtype=None):
         cell = {}
         self._alloc.append((cell, tuple(shape), dtype))
         return cell
@@ -238,8 +238,8 @@ class Graph(object):
         C0 = x.a.src.shape[3] if x.kind == 'cat' else 0
         p = ops.conv_problem(N, H, W, cin_dev, cout_dev, k, s, padding, C0=C0)
         y = Val(self, 'conv', (N, p.Ho, p.Wo, cout_dev), x=x, wp=wp, bp=bp, p=p, f32=use_bias, filters=filters)
-        y.cell = self._buffer(y.shape, torch.float32 if use_bias else torch.bfloat16)
-        y.dy_cell = self._buffer(y.shape, torch.bfloat16)
+        y.cell = self._buffer(y.shape, torch.float32 if use_bias else backend.torch_dtype())
+        y.dy_cell = self._buffer(y.shape, backend.torch_dtype())
         y.stat_rows = ops.conv2d_stat_rows(p)
         y.stat_cell = None if use_bias else self._buffer((2, y.stat_rows, cout_dev), torch.float32)
         y.wants_stats = False
@@ -362,19 +362,19 @@ class Graph(object):
         self.heads = heads
         self.ps.allocate(dev)
         for cell, shape, dtype in self._alloc:
-            cell['t'] = torch.zeros(shape, dtype=dtype, device=dev)
+            cell['t'] = torch.zeros(shape, dtype=dtype if dtype is not None else backend.torch_dtype(), device=dev)
         for bn in self.bn_groups:
             bn.allocate(dev, self.ps)
         N, H, W, C = self.input_val.shape
         self.images = torch.zeros(N, H, W, C, device=dev)
-        self.input_val.buf = torch.zeros(N, H, W, 8, dtype=torch.bfloat16, device=dev)
+        self.input_val.buf = torch.zeros(N, H, W, 8, dtype=backend.torch_dtype(), device=dev)
         # dgrad weight copies
         n_dg = 0
         for op in self.tape:
             if isinstance(op, ConvOp) and op.needs_dgrad():
                 op.dg_off = n_dg
                 n_dg += _round_up(op.y.wp.numel, SLOT)
-        self.w_dgrad = torch.zeros(max(n_dg, SLOT), dtype=torch.bfloat16, device=dev)
+        self.w_dgrad = torch.zeros(max(n_dg, SLOT), dtype=backend.torch_dtype(), device=dev)
         # one slab workspace for the two-phase weight gradients (they run back to back on one stream)
         ws_bytes = max([ops.conv2d_wgrad_workspace_bytes(op.y.p) for op in self.tape if isinstance(op, ConvOp)] +
                        [ops.dwconv_mix_wgrad_workspace_bytes(op.y.mp) for op in self.tape if isinstance(op, MixConvOp)] + [16])
@@ -541,7 +541,7 @@ class ConvOp(object):
             return
         x = y.x
         if x.kind == 'cat':
-            self.dcat = torch.zeros(x.shape, dtype=torch.bfloat16, device=self.g.dev)
+            self.dcat = torch.zeros(x.shape, dtype=backend.torch_dtype(), device=self.g.dev)
             a, b = x.a.src, x.b
             self.acc = [a.grad_init, b.grad_init]
             a.grad_init = b.grad_init = True

@@ -249,7 +249,7 @@ def pack_input(images, out, npix, cimg):
 
 def make_loss_config(head_grid_sizes, class_num, anchor_boxes, iou_thresh, loss_weights, ldc, T,
                      rectified_coord_num=0, rectified_loss_weight=None, is_focal_loss=False, focal_alpha=0.25,
-                     focal_gamma=2.0, is_tiou_recall=False, eps=1e-8):
+                     focal_gamma=2.0, is_tiou_recall=False, eps=1e-8, grad_scale16=1.0):
     c = LossConfig()
     lw = np.asarray(loss_weights, dtype=np.float32)
     if rectified_loss_weight is None:
@@ -272,6 +272,7 @@ def make_loss_config(head_grid_sizes, class_num, anchor_boxes, iou_thresh, loss_
     c.focal_alpha, c.focal_gamma = focal_alpha, focal_gamma
     c.is_tiou_recall = int(bool(is_tiou_recall))
     c.eps = eps
+    c.grad_scale16 = float(grad_scale16)
     return c
 
 

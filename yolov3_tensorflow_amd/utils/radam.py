@@ -52,7 +52,7 @@ class RAdam(object):
         ps = model.g.ps
         ops.radam_schedule(self.sched, self._iterations, self.beta_1, self.beta_2, self.initial_decay, self.warmup_coef)
         ops.radam_l2_step(ps.flat, ps.grad, ps.m, ps.v, ps.l2_table, ps.n, self.sched, self.beta_1, self.beta_2, self.epsilon,
-                          grad_scale=1.0 / model.world_size, zero_grad=True, params_bf16=ps.bf16, vhat=self.vhat,
+                          grad_scale=1.0 / (model.world_size * backend.loss_scale()), zero_grad=True, params_bf16=ps.bf16, vhat=self.vhat,
                           l2_partial=self.l2_partial)
         # reported loss = YOLOv3 loss + sum of L2 regularisers (what keras' compiled loss contains)
         ops.sum_partials(self.l2_partial, self.l2_partial.numel(), None, model.l2_value)

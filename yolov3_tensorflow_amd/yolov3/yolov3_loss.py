@@ -36,7 +36,7 @@ class YOLOv3Loss(object):
                                     ldc, T, rectified_coord_num=self.rectified_coord_num,
                                     rectified_loss_weight=self.rectified_loss_weight, is_focal_loss=self.is_focal_loss,
                                     focal_alpha=self.focal_alpha, focal_gamma=self.focal_gamma,
-                                    is_tiou_recall=self.is_tiou_recall, eps=backend.epsilon())
+                                    is_tiou_recall=self.is_tiou_recall, eps=backend.epsilon(), grad_scale16=backend.loss_scale())
 
     def _alloc(self, dev, N, ldc, T):
         self.dev, self.N, self.ldc, self.T = dev, N, list(ldc), T
