@@ -187,8 +187,9 @@ def test_strip_conv_variants_match_implicit_gemm(dev, bm, bn):
     torch.testing.assert_close(got[3], ref[3], rtol=2 ** -6, atol=2e-3)
 
 
+@pytest.mark.parametrize('ring', [2, 3])
 @pytest.mark.parametrize('shape', [(3, 21, 19, 128, 256), (70, 13, 13, 64, 64), (2, 40, 104, 64, 128), (1, 5, 3, 64, 64)])
-def test_wgrad_strip_matches_generic(dev, shape):
+def test_wgrad_strip_matches_generic(dev, shape, ring):
     """the kernel-row strip weight gradient (3x3 / stride 1) against the generic im2col one: image boundaries and row wraps inside the
     64-pixel stages (13 x 13), maps wider than a stage (W = 104), a map smaller than the halo (5 x 3), two 64-channel slices, both
     output-channel tiles, atomics and two-phase modes"""
@@ -209,12 +210,14 @@ def test_wgrad_strip_matches_generic(dev, shape):
         return dw.cpu(), dw2.cpu()
 
     try:
+        ops.set_tuning('wgrad_ring', ring)
         ops.set_tuning('wgrad_strip', 0)
         ref = run()
         ops.set_tuning('wgrad_strip', 1)
         got = run()
     finally:
         ops.set_tuning('wgrad_strip', 1)
+        ops.set_tuning('wgrad_ring', 2)
     scale = ref[1].abs().max().item()
     for t in got:      # same bf16 products, float32 sums in a different order
         torch.testing.assert_close(t, ref[1], rtol=1e-4, atol=1e-5 * scale)
@@ -709,7 +712,7 @@ def test_fp16_build_conv_fwd_dgrad_wgrad(dev, fp16, case):
 
 def test_fp16_build_strip_and_wgrad_strip(dev, fp16):
     test_strip_conv_variants_match_implicit_gemm(dev, 128, 64)
-    test_wgrad_strip_matches_generic(dev, (3, 21, 19, 128, 256))
+    test_wgrad_strip_matches_generic(dev, (3, 21, 19, 128, 256), 2)
     test_bn_act_fwd_bwd(dev, 'res_bn')
     test_bn_pool_relu_fwd_bwd(dev)
     test_mixconv_fwd_dgrad_wgrad(dev, 128, 2, 11, 9)

@@ -7,7 +7,7 @@ for path in sys.argv[1:]:
     d = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         n = r['Kernel_Name']
-        if 'igemm' not in n and 'bn_' not in n:
+        if 'igemm' not in n and 'bn_' not in n and 'strip' not in n:
             continue
         n = re.sub(r'\(anonymous namespace\)::', '', n); n = re.sub(r'^void ', '', n).split('(')[0]
         key = (n, r['Grid_Size'], r['Workgroup_Size'])

@@ -766,7 +766,7 @@ struct WgradStripArgs {
 
 __device__ __forceinline__ int wgx_f(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
-template <int BCO>
+template <int BCO, int NST>
 __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, float* __restrict__ out) {
   constexpr int COT = BCO / 32;               // 16-row co tiles per wave (8 waves: 2 along co x 4 along ci)
   constexpr int XROWS = 72;                   // 66 needed, 9 LDS-DMA instructions of 8 rows
@@ -781,8 +781,10 @@ __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, f
   const int s_begin = bid.z * a.steps_per_split;
   const int s_end = min(nsteps, s_begin + a.steps_per_split);
   if (s_begin >= s_end) return;
-  char* const sZero = smem + 2 * STAGE;
-  if (tid < 8) *reinterpret_cast<uint4*>(sZero + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  // zero rows (redirect target of invalid taps); with NST == 3 also the landing zone (1 KB of zeros) of the dummy out-of-range load
+  // that keeps the number of loads per stage the same on every wave, so that s_waitcnt vmcnt can leave one stage in flight
+  char* const sZero = smem + NST * STAGE;
+  if (tid < 64) *reinterpret_cast<uint4*>(sZero + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
   constexpr unsigned OOB = 0x80000000u;
   const int hw = a.H * a.W;
 
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, f
       const int row = pbase + (k & 1) * 4 + (k >> 1) * 32 + s;
       xaddr[k][s] = row * 128 + ((wc ^ wgx_f(row)) << 5) + (i16 & 3) * 8;
     }
-  const int zaddr = 2 * STAGE;                         // relative to smem
+  const int zaddr = NST * STAGE;                       // relative to smem
   // x coordinate of output pixel s_begin*64 + pbase
   int x0;
   {
@@ -847,7 +849,9 @@ __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, f
     char* sY = sX + XIMG + wave * 2048;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      if (u == 0 || wave == 0) {
+      if (NST == 3 && u == 1 && wave != 0) {
+        buffer_load_lds16(a.x, a.x_bytes, sZero, OOB);      // count-keeping dummy: zeros onto the zero rows
+      } else if (u == 0 || wave == 0) {
         buffer_load_lds16(a.x, a.x_bytes, sX + (u == 0 ? wave : 8) * 1024, xy[u] == bad_y ? OOB : (unsigned)xoff[u]);
         xoff[u] += xstep;
         const int w2 = xx[u] + a.dw;
@@ -899,14 +903,30 @@ __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, f
     x0 -= x0 >= a.W ? a.W : 0;
   };
 
-  issue_stage(0);
-  for (int st = s_begin; st < s_end; ++st) {
-    const int buf = (st - s_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // loads landed; this wave's reads of the buffer refilled next completed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (st + 1 < s_end) issue_stage(buf ^ 1);
-    compute_stage(buf);
+  if (NST == 2) {
+    issue_stage(0);
+    for (int st = s_begin; st < s_end; ++st) {
+      const int buf = (st - s_begin) & 1;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // loads landed; this wave's reads of the buffer refilled next completed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (st + 1 < s_end) issue_stage(buf ^ 1);
+      compute_stage(buf);
+    }
+  } else {
+    // three stages: stage st+1 stays in flight (4 loads per wave) while stage st is awaited; stage st+2 refills the buffer of stage st-1
+    issue_stage(0);
+    if (s_begin + 1 < s_end) issue_stage(1);
+    int buf = 0;
+    for (int st = s_begin; st < s_end; ++st) {
+      if (st + 1 < s_end) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (st + 2 < s_end) issue_stage(buf == 0 ? 2 : buf - 1);
+      compute_stage(buf);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
   }
 
   // D[row = co][col = ci]: lane holds rows 4*(lane>>4)+j, column lane&15
@@ -1051,6 +1071,7 @@ TileCfg pick_tile(int M, int Kout) {
 // strip kernel plan: 0 = not eligible, else the pixel tile BM (and the channel tile through *bnp)
 // tuning overrides (yolo_set_tuning): strip_bm = -1 auto, 0 = never use the strip kernel, 64 / 128 / 256 = force; strip_bn = 0 auto
 int g_strip_bm = -1, g_strip_bn = 0;
+int g_wgrad_ring = 2;    // "wgrad_ring": stages of the strip weight-gradient's operand ring (2 or 3)
 int g_wgrad_xcd = 1;     // "wgrad_xcd": 1 = 1-D weight-gradient grids with one contiguous run of logical blocks per XCD, 0 = plain 3-D grid
 int g_strip_ws = 0;      // "strip_ws": 0 auto, 2 / 3 force the weight-ring depth of the strip kernel
 // workgroups aimed at by the two-phase path: 1.5 per CU measured best on the whole step (256 / 384 / 512 tried: fewer slabs to sum
@@ -1198,6 +1219,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "s2_classes")) { YOLO_CHECK_ARG(value == 0 || value == 1, "s2_classes"); g_s2_classes = value; }
   else if (!strcmp(name, "wgrad_target")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "wgrad_target"); g_wgrad_target = value; }
   else if (!strcmp(name, "bn_fused_small_grid")) { YOLO_CHECK_ARG(value == 0 || (value >= 16 && value <= 255), "bn_fused_small_grid"); g_fused_small_chunks = value; }
+  else if (!strcmp(name, "wgrad_ring")) { YOLO_CHECK_ARG(value == 2 || value == 3, "wgrad_ring"); g_wgrad_ring = value; }
   else if (!strcmp(name, "wgrad_xcd")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_xcd"); g_wgrad_xcd = value; }
   else if (!strcmp(name, "strip_ws")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 3, "strip_ws"); g_strip_ws = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
@@ -1313,9 +1335,21 @@ void launch_wgrad(const yolo_conv_problem* p, const WgradPlan& pl, const void* d
     a.rhw = g.rhw; a.rw = g.rw; a.slab = slab; a.steps_per_split = pl.sps;
     a.gx = pl.tiles_k; a.gy = pl.tiles_c; a.xcd = g_wgrad_xcd;
     const dim3 grid = g_wgrad_xcd ? dim3(pl.tiles_k * pl.tiles_c * pl.split_k) : dim3(pl.tiles_k, pl.tiles_c, pl.split_k);
-    const size_t lds = 2 * (72 * 128 + WG_BP * 256) + 128;
-    if (pl.bco == 128) hipLaunchKernelGGL(wgrad3x3_strip_kernel<128>, grid, dim3(512), lds, stream, a, out);
-    else               hipLaunchKernelGGL(wgrad3x3_strip_kernel<64>, grid, dim3(512), lds, stream, a, out);
+    const int nst = g_wgrad_ring == 3 ? 3 : 2;
+    const size_t lds = (size_t)nst * (72 * 128 + WG_BP * 256) + 1024;
+    if (nst == 3) {
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_strip_kernel<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_strip_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+      }
+      if (pl.bco == 128) hipLaunchKernelGGL((wgrad3x3_strip_kernel<128, 3>), grid, dim3(512), lds, stream, a, out);
+      else               hipLaunchKernelGGL((wgrad3x3_strip_kernel<64, 3>), grid, dim3(512), lds, stream, a, out);
+      return;
+    }
+    if (pl.bco == 128) hipLaunchKernelGGL((wgrad3x3_strip_kernel<128, 2>), grid, dim3(512), lds, stream, a, out);
+    else               hipLaunchKernelGGL((wgrad3x3_strip_kernel<64, 2>), grid, dim3(512), lds, stream, a, out);
     return;
   }
   const size_t lds = 2 * 2 * WG_BP * 256;
