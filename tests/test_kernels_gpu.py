@@ -392,7 +392,8 @@ def test_bn_act_fwd_bwd(dev, mode):
 
 @pytest.mark.parametrize('M,Cc,mode', [(32 * 13 * 13, 512, 'plain'), (32 * 26 * 26, 256, 'res'), (32 * 52 * 52, 128, 'bn2'),
                                        (3001, 64, 'res_acc'), (32 * 104 * 104, 64, 'plain'), (32 * 104 * 104 * 2, 64, 'too_big')])
-def test_bn_bwd_fused_matches_three_kernel_path(dev, M, Cc, mode):
+@pytest.mark.parametrize('small_grid', [0, 128])
+def test_bn_bwd_fused_matches_three_kernel_path(dev, M, Cc, mode, small_grid):
     """the single-launch BatchNorm backward (resident grid, device-wide hand-off) against reduce / finalize / apply on the same inputs:
     plain BN+ReLU, identity residual (with and without fan-in accumulation), shortcut-BN branch, 2 / 6 / 11 chunks per thread, a ragged
     size, and the size it has to refuse; two launches in a row reuse the (monotonic) barrier word"""
@@ -427,7 +428,11 @@ def test_bn_bwd_fused_matches_three_kernel_path(dev, M, Cc, mode):
         kw.update(dres=dres_ref, acc_dres=acc)
     ops.bn_act_bwd_apply(dout, out, True, M, Cc, y=y, a1=a1, mean=mean, rstd=rstd, k1=k1, k2=k2, dy=dy_ref, acc_dy=acc, **kw)
 
-    ops.set_tuning('bn_fused_min_chunks', 1)          # also exercise the small sizes the heuristic leaves to the three-kernel path
+    # small sizes: either force them onto the full grid (min chunks 1) or send them to the fixed small grid with its own counters
+    need_full = -(-(M * (Cc // 8)) // (256 * 1024))
+    on_small = bool(small_grid) and need_full < 3
+    ops.set_tuning('bn_fused_min_chunks', 3 if small_grid else 1)
+    ops.set_tuning('bn_fused_small_grid', small_grid)
     ws = torch.zeros(ops.bn_bwd_fused_workspace_floats(Cc), device=dev)
     sync = torch.zeros(ops.bn_bwd_fused_sync_words(), dtype=torch.int32, device=dev)
     for rep in range(2):
@@ -444,11 +449,14 @@ def test_bn_bwd_fused_matches_three_kernel_path(dev, M, Cc, mode):
         if mode == 'too_big':
             assert not ok
             ops.set_tuning('bn_fused_min_chunks', 3)
+            ops.set_tuning('bn_fused_small_grid', 0)
             return
         assert ok
         torch.cuda.synchronize()
         assert ops.bn_fused_timeouts(sync) == 0
-        assert int(sync[0]) > 0 and int(sync[0]) % (2 * (rep + 1)) == 0      # shard 0: two grid barriers per launch
+        first = int(sync[sync.numel() // 2 if on_small else 0])               # shard 0 of the counter set this grid size uses
+        assert first > 0 and first % (2 * (rep + 1)) == 0                     # two grid barriers per launch
+        assert int(sync[0 if on_small else sync.numel() // 2]) == 0           # the other set is untouched
         scale = max(dg.abs().max().item(), 1.0)
         torch.testing.assert_close(fdg, dg, rtol=2e-4, atol=2e-5 * scale)
         torch.testing.assert_close(fdb, db, rtol=2e-4, atol=2e-5 * max(db.abs().max().item(), 1.0))
@@ -460,6 +468,7 @@ def test_bn_bwd_fused_matches_three_kernel_path(dev, M, Cc, mode):
         if res:
             assert torch.equal(dres, dres_ref) or torch.allclose(dres.float(), dres_ref.float(), rtol=2 ** -8, atol=0)
     ops.set_tuning('bn_fused_min_chunks', 3)
+    ops.set_tuning('bn_fused_small_grid', 0)
 
 
 def test_bn_pool_relu_fwd_bwd(dev):
