@@ -638,7 +638,11 @@ __global__ __launch_bounds__(FB_THREADS) void bn_bwd_fused_kernel(FusedBwdArgs a
     mu2[j] = HAS2 ? a.mean2[c0 + j] : 0.f; rs2[j] = HAS2 ? a.rstd2[c0 + j] : 0.f;
   }
   // ---- phase 1: masked gradient into registers, per-thread sums
+  // MAXCH <= 6: the conv outputs y are kept in registers too (24 more VGPRs), so phase 2 re-reads nothing; with 11 chunks per thread both
+  // would not fit the 128 VGPRs a 1024-thread workgroup may use, and y is read again (from the Infinity Cache) in phase 2
+  constexpr bool KEEP_Y = MAXCH <= 2 || (MAXCH <= 6 && !HAS2);
   uint4 gk[MAXCH];
+  uint4 yk[KEEP_Y ? MAXCH : 1];
   float acc[3][8] = {};
 #pragma unroll
   for (int k = 0; k < MAXCH; ++k) {
@@ -661,7 +665,9 @@ __global__ __launch_bounds__(FB_THREADS) void bn_bwd_fused_kernel(FusedBwdArgs a
       gk[k] = d;
       float g[8], v[8];
       unpack_bf8(d, g);
-      unpack_bf8(ld16(a.y + i * 8), v);
+      const uint4 yv = ld16(a.y + i * 8);
+      if (KEEP_Y) yk[k] = yv;
+      unpack_bf8(yv, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { acc[0][j] += g[j]; acc[1][j] += g[j] * ((v[j] - mu[j]) * rs[j]); }
       if (HAS2) {
@@ -750,7 +756,7 @@ __global__ __launch_bounds__(FB_THREADS) void bn_bwd_fused_kernel(FusedBwdArgs a
     if (i < a.total) {
       float g[8], v[8], o[8];
       unpack_bf8(gk[k], g);
-      unpack_bf8(ld16(a.y + i * 8), v);
+      unpack_bf8(KEEP_Y ? yk[KEEP_Y ? k : 0] : ld16(a.y + i * 8), v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = A[j] * g[j] + (B[j] * v[j] + D[j]);
       if (a.acc_dy) {
