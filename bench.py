@@ -158,6 +158,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'], help='16-bit compute type: bf16 (default) or fp16 (libyolov3_amd_fp16.so + '
                     'static loss scaling; BASELINE.json configs[4])')
     ap.add_argument('--focal', action='store_true', help='focal loss on (BASELINE.json configs[4])')
+    ap.add_argument('--wgrad-batch', type=int, default=None, help='weight gradients per hand-off to the side stream (engine default 2)')
     ap.add_argument('--no-fused-bn', action='store_true', help='three-kernel BatchNorm backward instead of the single-launch one')
     args = ap.parse_args()
 
@@ -180,6 +181,8 @@ def main():
     model.use_hip_graph = bool(args.graph)
     model.overlap_wgrad = not args.no_overlap
     model.g.fused_bn_bwd = not args.no_fused_bn
+    if args.wgrad_batch is not None:
+        model.g.wgrad_batch = max(1, args.wgrad_batch)
     from yolov3_tensorflow_amd import ops
     for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):      # kernel-selection overrides for A/B runs (yolo_set_tuning)
         k, v = kv.split('=')

@@ -187,8 +187,8 @@ def test_strip_conv_variants_match_implicit_gemm(dev, bm, bn):
     torch.testing.assert_close(got[3], ref[3], rtol=2 ** -6, atol=2e-3)
 
 
-@pytest.mark.parametrize('ring', [2, 3])
-@pytest.mark.parametrize('shape', [(3, 21, 19, 128, 256), (70, 13, 13, 64, 64), (2, 40, 104, 64, 128), (1, 5, 3, 64, 64)])
+@pytest.mark.parametrize('ring', [2, 3, 'pipe'])
+@pytest.mark.parametrize('shape', [(3, 21, 19, 128, 256), (70, 13, 13, 64, 64), (2, 40, 104, 64, 128), (1, 5, 3, 64, 64), (8, 13, 13, 128, 128)])
 def test_wgrad_strip_matches_generic(dev, shape, ring):
     """the kernel-row strip weight gradient (3x3 / stride 1) against the generic im2col one: image boundaries and row wraps inside the
     64-pixel stages (13 x 13), maps wider than a stage (W = 104), a map smaller than the halo (5 x 3), two 64-channel slices, both
@@ -210,7 +210,8 @@ def test_wgrad_strip_matches_generic(dev, shape, ring):
         return dw.cpu(), dw2.cpu()
 
     try:
-        ops.set_tuning('wgrad_ring', ring)
+        ops.set_tuning('wgrad_pipe', 1 if ring == 'pipe' else 0)          # software-pipelined stage body (double-buffered) or the plain loop
+        ops.set_tuning('wgrad_ring', 2 if ring == 'pipe' else ring)
         ops.set_tuning('wgrad_strip', 0)
         ref = run()
         ops.set_tuning('wgrad_strip', 1)
@@ -218,6 +219,7 @@ def test_wgrad_strip_matches_generic(dev, shape, ring):
     finally:
         ops.set_tuning('wgrad_strip', 1)
         ops.set_tuning('wgrad_ring', 2)
+        ops.set_tuning('wgrad_pipe', 1)
     scale = ref[1].abs().max().item()
     for t in got:      # same bf16 products, float32 sums in a different order
         torch.testing.assert_close(t, ref[1], rtol=1e-4, atol=1e-5 * scale)

@@ -15,6 +15,7 @@
 //                    so fragments are read with ds_read_b64_tr_b16 (hardware transpose); split over pixel ranges,
 //                    fp32 atomics into dW.
 #include "common.h"
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -766,8 +767,8 @@ struct WgradStripArgs {
 
 __device__ __forceinline__ int wgx_f(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
-template <int BCO, int NST>
-__global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, float* __restrict__ out) {
+template <int BCO, int NST, bool PIPE = false>
+__global__ __launch_bounds__(512, 4) void wgrad3x3_strip_kernel(WgradStripArgs a, float* __restrict__ out) {
   constexpr int COT = BCO / 32;               // 16-row co tiles per wave (8 waves: 2 along co x 4 along ci)
   constexpr int XROWS = 72;                   // 66 needed, 9 LDS-DMA instructions of 8 rows
   constexpr int XIMG = XROWS * 128, YIMG = WG_BP * 256, STAGE = XIMG + YIMG;
@@ -903,7 +904,106 @@ __global__ __launch_bounds__(512) void wgrad3x3_strip_kernel(WgradStripArgs a, f
     x0 -= x0 >= a.W ? a.W : 0;
   };
 
-  if (NST == 2) {
+  if constexpr (PIPE) {
+    // Software-pipelined variant (NST == 2).  The waves of a workgroup run in lockstep behind the per-stage barrier, so with the plain
+    // loop every wave on a SIMD is in its VALU phase (cursor updates, tap-validity selects, address adds: ~100 VALU per stage) or in its
+    // MFMA phase (24 MFMAs) at the same time and the two phases add up instead of overlapping (measured: the kernel is insensitive to
+    // ring depth and to LDS-read ILP, and 1.2x faster with this body at equal occupancy).  Here the per-lane LDS addresses are
+    // stage-invariant registers (buffer, half-step and pixel-group offsets are compile-time constants that fold into the DS offset
+    // field), and the only per-stage VALU work -- the loads and the tap-validity selects of the NEXT stage -- is branch-free, independent
+    // of the current stage's MFMAs and in the same scheduling region, so the scheduler slots it between them.
+    static_assert(NST == 2, "pipelined variant is double-buffered");
+    typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    int ya[COT][2];                                        // dY fragment addresses of half step 0 (half step 1: + 32 rows, same swizzle)
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+      const int col0 = wr * (BCO / 2) + c * 16;
+      const int r0 = 8 * gq + (i16 >> 2), r1 = r0 + 4;
+      const int ch = (col0 >> 3) + ((i16 & 3) >> 1), hb = (i16 & 1) << 3;
+      ya[c][0] = XIMG + r0 * 256 + ((ch ^ wg_f(r0)) << 4) + hb;
+      ya[c][1] = XIMG + r1 * 256 + ((ch ^ wg_f(r1)) << 4) + hb;
+    }
+    // X fragment addresses: xaddr[k][s] with k = 2 * ks + lohi; half step 1 = half step 0 + 32 strip rows (bits 1 and 3 of the row, which
+    // the swizzle uses, do not change): only xaddr[0..1][s] are kept
+    int xs[2][2][2];                                       // selected addresses of the side taps (s = 0, 2) of the stage being read: [ks][side][lohi]
+    auto select_x = [&](auto bufc) {                       // for the stage whose first pixel has column x0; advances x0 by 64 pixels
+      constexpr int B = decltype(bufc)::value;
+      constexpr int zrel = NST * STAGE - B * STAGE;        // the zero rows, seen from this buffer's base
+      int xk[4];
+      xk[0] = x0;
+      xk[1] = x0 + a.d4;  xk[1] -= xk[1] >= a.W ? a.W : 0;
+      xk[2] = x0 + a.d32; xk[2] -= xk[2] >= a.W ? a.W : 0;
+      xk[3] = x0 + a.d36; xk[3] -= xk[3] >= a.W ? a.W : 0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int col = xk[2 * ks + h];
+          xs[ks][0][h] = col == 0 ? zrel : xaddr[h][0] + ks * 4096;
+          xs[ks][1][h] = col == a.W - 1 ? zrel : xaddr[h][2] + ks * 4096;
+        }
+      x0 += a.dw;
+      x0 -= x0 >= a.W ? a.W : 0;
+    };
+    // branch-free loads of the next stage: every wave issues 4 instructions (the ninth strip instruction belongs to wave 0; the other
+    // waves aim theirs out of range at the zero rows); past the last stage of this split the loads fetch the next split's pixels (or
+    // zeros beyond the tensor) into the buffer nobody reads any more
+    const unsigned x1_mask = wave == 0 ? 0u : OOB;
+    auto issue_next = [&](auto bufc) {
+      constexpr int B = decltype(bufc)::value;
+      char* sX = smem + B * STAGE;
+      buffer_load_lds16(a.x, a.x_bytes, sX + wave * 1024, xy[0] == bad_y ? OOB : (unsigned)xoff[0]);
+      buffer_load_lds16(a.x, a.x_bytes, wave == 0 ? sX + 8 * 1024 : sZero, (xy[1] == bad_y ? OOB : (unsigned)xoff[1]) | x1_mask);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        xoff[u] += xstep;
+        const int w2 = xx[u] + a.dw;
+        const int cw = w2 >= a.W;
+        xx[u] = w2 - (cw ? a.W : 0);
+        const int h2 = xy[u] + a.dh + cw;
+        xy[u] = h2 - (h2 >= a.H ? a.H : 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        buffer_load_lds16(a.dy, a.y_bytes, sX + XIMG + wave * 2048 + j * 1024, y_cv[j] ? yoff[j] : OOB);
+        yoff[j] += ystep;
+      }
+    };
+    auto rd = [&](const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)p); };
+    auto pack = [&](s16x4_t lo, s16x4_t hi) {
+      s16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8_t, r);
+    };
+    auto body = [&](auto bufc) {
+      constexpr int B = decltype(bufc)::value;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this stage landed; this wave's reads of the other buffer completed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* base = smem + B * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t yf[COT], xf[3];
+#pragma unroll
+        for (int c = 0; c < COT; ++c) yf[c] = pack(rd(base + ya[c][0] + ks * 8192), rd(base + ya[c][1] + ks * 8192));
+        xf[0] = pack(rd(base + xs[ks][0][0]), rd(base + xs[ks][0][1]));
+        xf[1] = pack(rd(base + xaddr[0][1] + ks * 4096), rd(base + xaddr[1][1] + ks * 4096));
+        xf[2] = pack(rd(base + xs[ks][1][0]), rd(base + xs[ks][1][1]));
+        if (ks == 0) issue_next(std::integral_constant<int, (B ^ 1)>{});
+        else         select_x(std::integral_constant<int, (B ^ 1)>{});
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) acc[c][s] = YOLO_MFMA_16x16x32(yf[c], xf[s], acc[c][s]);
+      }
+    };
+    issue_next(std::integral_constant<int, 0>{});
+    select_x(std::integral_constant<int, 0>{});
+    for (int st = s_begin; st < s_end; st += 2) {
+      body(std::integral_constant<int, 0>{});
+      if (st + 1 < s_end) body(std::integral_constant<int, 1>{});
+    }
+  } else if (NST == 2) {
     issue_stage(0);
     for (int st = s_begin; st < s_end; ++st) {
       const int buf = (st - s_begin) & 1;
@@ -1071,6 +1171,7 @@ TileCfg pick_tile(int M, int Kout) {
 // strip kernel plan: 0 = not eligible, else the pixel tile BM (and the channel tile through *bnp)
 // tuning overrides (yolo_set_tuning): strip_bm = -1 auto, 0 = never use the strip kernel, 64 / 128 / 256 = force; strip_bn = 0 auto
 int g_strip_bm = -1, g_strip_bn = 0;
+int g_wgrad_pipe = 1;    // "wgrad_pipe": software-pipelined stage body of the strip weight gradient (next stage's VALU work under the MFMAs)
 int g_wgrad_ring = 2;    // "wgrad_ring": stages of the strip weight-gradient's operand ring (2 or 3)
 int g_wgrad_xcd = 1;     // "wgrad_xcd": 1 = 1-D weight-gradient grids with one contiguous run of logical blocks per XCD, 0 = plain 3-D grid
 int g_strip_ws = 0;      // "strip_ws": 0 auto, 2 / 3 force the weight-ring depth of the strip kernel
@@ -1219,6 +1320,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "s2_classes")) { YOLO_CHECK_ARG(value == 0 || value == 1, "s2_classes"); g_s2_classes = value; }
   else if (!strcmp(name, "wgrad_target")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "wgrad_target"); g_wgrad_target = value; }
   else if (!strcmp(name, "bn_fused_small_grid")) { YOLO_CHECK_ARG(value == 0 || (value >= 16 && value <= 255), "bn_fused_small_grid"); g_fused_small_chunks = value; }
+  else if (!strcmp(name, "wgrad_pipe")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_pipe"); g_wgrad_pipe = value; }
   else if (!strcmp(name, "wgrad_ring")) { YOLO_CHECK_ARG(value == 2 || value == 3, "wgrad_ring"); g_wgrad_ring = value; }
   else if (!strcmp(name, "wgrad_xcd")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_xcd"); g_wgrad_xcd = value; }
   else if (!strcmp(name, "strip_ws")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 3, "strip_ws"); g_strip_ws = value; }
@@ -1346,6 +1448,11 @@ void launch_wgrad(const yolo_conv_problem* p, const WgradPlan& pl, const void* d
       }
       if (pl.bco == 128) hipLaunchKernelGGL((wgrad3x3_strip_kernel<128, 3>), grid, dim3(512), lds, stream, a, out);
       else               hipLaunchKernelGGL((wgrad3x3_strip_kernel<64, 3>), grid, dim3(512), lds, stream, a, out);
+      return;
+    }
+    if (g_wgrad_pipe) {
+      if (pl.bco == 128) hipLaunchKernelGGL((wgrad3x3_strip_kernel<128, 2, true>), grid, dim3(512), lds, stream, a, out);
+      else               hipLaunchKernelGGL((wgrad3x3_strip_kernel<64, 2, true>), grid, dim3(512), lds, stream, a, out);
       return;
     }
     if (pl.bco == 128) hipLaunchKernelGGL((wgrad3x3_strip_kernel<128, 2>), grid, dim3(512), lds, stream, a, out);
