@@ -158,7 +158,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'], help='16-bit compute type: bf16 (default) or fp16 (libyolov3_amd_fp16.so + '
                     'static loss scaling; BASELINE.json configs[4])')
     ap.add_argument('--focal', action='store_true', help='focal loss on (BASELINE.json configs[4])')
-    ap.add_argument('--wgrad-batch', type=int, default=None, help='weight gradients per hand-off to the side stream (engine default 2)')
+    ap.add_argument('--wgrad-batch', type=int, default=None, help='weight gradients per hand-off to the side stream (engine default 4)')
+    ap.add_argument('--wgrad-gflop', type=float, default=None, help='also hand over when the pending weight gradients reach this many GFLOP')
     ap.add_argument('--no-fused-bn', action='store_true', help='three-kernel BatchNorm backward instead of the single-launch one')
     args = ap.parse_args()
 
@@ -183,6 +184,8 @@ def main():
     model.g.fused_bn_bwd = not args.no_fused_bn
     if args.wgrad_batch is not None:
         model.g.wgrad_batch = max(1, args.wgrad_batch)
+    if args.wgrad_gflop is not None:
+        model.g.wgrad_cost_limit = args.wgrad_gflop
     from yolov3_tensorflow_amd import ops
     for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):      # kernel-selection overrides for A/B runs (yolo_set_tuning)
         k, v = kv.split('=')

@@ -193,8 +193,9 @@ class Graph(object):
         self._alloc = []
         self._repack_table = None
         self.wgrad_stream = None
-        self.wgrad_batch = 2               # weight gradients per main->side stream hand-off (see on_wgrad_stream)
+        self.wgrad_batch = 4               # at most this many weight gradients per main->side stream hand-off (see on_wgrad_stream)
         self._wgrad_pending = []
+        self._wgrad_cost, self.wgrad_cost_limit = 0.0, 18.0   # ... or as soon as the pending ones reach this many GFLOP (a big 3x3 layer goes alone)
         self.bucket_cut, self.bucket_offset, self.on_bucket = -1, 0, None
 
     # ------------------------------------------------------------------------------------------------ allocation helpers
@@ -479,17 +480,19 @@ class Graph(object):
         self._repack_event = torch.cuda.Event()
         self._repack_event.record(self.wgrad_stream)
 
-    def on_wgrad_stream(self, fn, flush=False):
+    def on_wgrad_stream(self, fn, flush=False, cost=0.0):
         """run fn() on the weight-gradient stream after everything enqueued so far on the current stream.  Hand-offs are BATCHED: an
         event record on the main stream plus the wait on the side stream stalls the main stream for ~15-25 us on this runtime (measured,
         tools/probes/event_cost.py: 4.7 us per kernel in a plain chain, 28 us with a hand-off after each), so the weight gradients of
-        ``wgrad_batch`` consecutive layers share one event -- their dY buffers are static, they only have to run before the optimizer"""
+        consecutive layers share one event (up to ``wgrad_batch`` of them, or ``wgrad_cost_limit`` GFLOP: the small 1x1 / stride-2 layers ride along
+        with the next big one) -- their dY buffers are static, they only have to run before the optimizer"""
         side = self.wgrad_stream
         if side is None:
             fn()
             return
         self._wgrad_pending.append(fn)
-        if flush or len(self._wgrad_pending) >= self.wgrad_batch:
+        self._wgrad_cost += cost
+        if flush or len(self._wgrad_pending) >= self.wgrad_batch or (self.wgrad_cost_limit and self._wgrad_cost >= self.wgrad_cost_limit):
             self.flush_wgrad()
 
     def flush_wgrad(self):
@@ -497,6 +500,7 @@ class Graph(object):
         if not self._wgrad_pending:
             return
         pending, self._wgrad_pending = self._wgrad_pending, []
+        self._wgrad_cost = 0.0
         if side is None:
             for fn in pending:
                 fn()
@@ -584,7 +588,8 @@ class ConvOp(object):
 
     def backward(self):
         y = self.y
-        self.g.on_wgrad_stream(self._wgrad)
+        p = y.p
+        self.g.on_wgrad_stream(self._wgrad, cost=2e-9 * p.N * p.Ho * p.Wo * p.Cout * p.Cin * p.R * p.S)
         if not self.needs_dgrad():
             return
         x = y.x
