@@ -178,6 +178,10 @@ def main():
         dist.init_process_group('nccl')
 
     H = W = args.size
+    from yolov3_tensorflow_amd import ops
+    for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):      # kernel-selection overrides for A/B runs (yolo_set_tuning);
+        k, v = kv.split('=')                                                 # before the model is built: workspaces are sized from the plans
+        ops.set_tuning(k, int(v))
     model, loss, opt, grids = build_model(args.backbone, H, W, args.batch, args.classes, device, focal=args.focal)
     model.use_hip_graph = bool(args.graph)
     model.overlap_wgrad = not args.no_overlap
@@ -186,10 +190,6 @@ def main():
         model.g.wgrad_batch = max(1, args.wgrad_batch)
     if args.wgrad_gflop is not None:
         model.g.wgrad_cost_limit = args.wgrad_gflop
-    from yolov3_tensorflow_amd import ops
-    for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):      # kernel-selection overrides for A/B runs (yolo_set_tuning)
-        k, v = kv.split('=')
-        ops.set_tuning(k, int(v))
     if world > 1:
         from yolov3_tensorflow_amd import parallel
         parallel.setup_data_parallel(model)
