@@ -59,8 +59,14 @@ typedef struct {
 int yolo_conv2d_stat_rows(const yolo_conv_problem* p);
 /* Test / benchmark hook: override a kernel-selection heuristic.  "strip_bm": -1 auto (default), 0 never use the LDS-resident strip
  * kernel for 3x3 stride-1 convolutions, 64 / 128 / 256 force its pixel tile; "strip_bn": 0 auto, 64 / 128; "wgrad_strip": 0 / 1;
- * "bn_fused_min_chunks": smallest per-thread chunk count (1..12, default 3) served by yolo_bn_act_bwd_fused.  Changes
- * yolo_conv2d_stat_rows() accordingly: set it before sizing statistics buffers. */
+ * "strip_ws": 0 auto / 2 / 3 weight-ring stages; "s2_classes": 0 / 1 stride-2 data gradient as four dense parity classes;
+ * "wgrad_target": workgroups the split-K plan aims at (64..4096, default 384; changes yolo_conv2d_wgrad_workspace_bytes);
+ * "wgrad_xcd": 0 / 1 XCD-chunked 1-D weight-gradient grids; "wgrad_ring": 2 / 3 operand stages and "wgrad_pipe": 0 / 1 software-pipelined
+ * stage body of the strip weight gradient; "bn_fused_min_chunks": smallest per-thread chunk count (1..12, default 3) served by the
+ * full grid of yolo_bn_act_bwd_fused; "bn_fused_small_grid": 0 (default: smaller tensors use the three-kernel path) or the fixed
+ * workgroup count (16..255) of a second, smaller cooperative grid with its own barrier counters -- set it once, before the first
+ * fused launch on a given sync_words buffer.  Tile choices change yolo_conv2d_stat_rows(): set them before sizing statistics buffers.
+ * Process-wide, not thread-safe: meant for A/B runs and tests. */
 int yolo_set_tuning(const char* name, int value);
 int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd, const float* bias,
                     void* y, int y_is_f32, float* stat_sum, float* stat_sq, void* stream);
