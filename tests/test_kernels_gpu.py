@@ -516,6 +516,37 @@ def test_bn_pool_relu_fwd_bwd(dev):
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize('shape', [(2, 70, 54, 64), (3, 33, 47, 32), (1, 16, 16, 64), (2, 208, 208, 64)], ids=str)
+def test_pool_bwd_scatter_equals_gather(dev, shape):
+    """the scatter form of the stem's pooled backward apply (four disjoint window classes, LDS float tile) adds the same contributions in
+    the same order as the gather form: bit-identical dy, on maps of several 16 x 16 tiles with ragged edges and both pad parities"""
+    from yolov3_tensorflow_amd import ops
+    from oracle.nets import same_pad
+    N, H, W, Cc = shape
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    y = bf(torch.randn(N, H, W, Cc, generator=g)).to(dev)
+    (pt, _), (pl, _) = same_pad(H, 3, 2), same_pad(W, 3, 2)
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    sc = (torch.rand(Cc, generator=g) - 0.3).to(dev)
+    sh, mean, rstd, k1, k2 = [(torch.randn(Cc, generator=g) * s).to(dev) for s in (0.1, 0.2, 1.0, 0.05, 0.05)]
+    out = torch.empty(N, Ho, Wo, Cc, dtype=ACT(), device=dev)
+    arg = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=dev)
+    ops.bn_pool_fwd(y, sc, sh, out, arg, N, H, W, Cc, Ho, Wo, pt, pl, True)
+    dout = bf(torch.randn(N, Ho, Wo, Cc, generator=g)).to(dev)
+    res = []
+    try:
+        for scatter in (0, 1):
+            ops.set_tuning('pool_scatter', scatter)
+            dy = torch.full((N, H, W, Cc), float('nan'), dtype=ACT(), device=dev)
+            ops.bn_pool_bwd_apply(dout, out, arg, True, y, sc, mean, rstd, k1, k2, dy, N, H, W, Cc, Ho, Wo, pt, pl)
+            torch.cuda.synchronize()
+            res.append(dy.float().cpu())
+    finally:
+        ops.set_tuning('pool_scatter', 1)
+    assert torch.isfinite(res[0]).all()
+    assert torch.equal(res[0], res[1])
+
+
 @pytest.mark.parametrize('f,N,H,W', [(64, 2, 11, 9), (128, 2, 11, 9), (64, 3, 40, 104), (512, 5, 13, 13), (256, 2, 26, 26), (64, 1, 3, 2)])
 def test_mixconv_fwd_dgrad_wgrad(dev, f, N, H, W):
     """mixed depthwise conv (mixnet18.py:38-45) vs 4 x F.conv2d(groups=C_g) on channel slices: ragged strips, several row tiles per

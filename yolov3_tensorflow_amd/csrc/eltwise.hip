@@ -569,6 +569,111 @@ __global__ __launch_bounds__(EW_THREADS) void bn_pool_bwd_apply_tiled_kernel(con
   }
 }
 
+// Scatter form of the same tile (C = 64 or less: the float32 gradient tile [16 x 16][C] fits 64 KB of LDS).  The gather above tests, for
+// every pre-pool element, the arg-max byte of each of its 1..4 covering windows (~150 VALU per 8-channel chunk: the kernel was VALU-bound at
+// 2.5 TB/s); here every pooled element adds its gradient to the ONE position its arg-max names, 4.5x fewer elements to look at.  Two windows
+// can name the same position, so the adds run in four barrier-separated passes over the window classes (dh == 2, dw == 2): windows of one
+// class have stride 2 and the same offset, hence disjoint targets -- plain LDS read-modify-writes, no atomics, deterministic.
+constexpr int PS_THREADS = 512;   // two 64 KB workgroups per CU: 16 waves
+__global__ __launch_bounds__(PS_THREADS) void bn_pool_bwd_apply_scatter_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+                                                                               const uint8_t* __restrict__ argmax, int relu,
+                                                                               const bf16_t* __restrict__ y, const float* __restrict__ a1,
+                                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                               const float* __restrict__ k1, const float* __restrict__ k2,
+                                                                               bf16_t* __restrict__ dy, int H, int W, int C, int Ho, int Wo,
+                                                                               int pt, int pl, int tiles_w, int tiles_h) {
+  extern __shared__ __attribute__((aligned(16))) char pool_smem[];
+  float* gt = reinterpret_cast<float*>(pool_smem);            // [PT_TILE * PT_TILE][C]
+  const int CV = C >> 3;
+  int b = blockIdx.x;
+  const int tw = b % tiles_w; b /= tiles_w;
+  const int th = b % tiles_h;
+  const int n = b / tiles_h;
+  const int h0 = th * PT_TILE, w0 = tw * PT_TILE;
+  const int ho0 = max(0, (h0 + pt - 1) >> 1), wo0 = max(0, (w0 + pl - 1) >> 1);
+  for (int i = threadIdx.x; i < PT_TILE * PT_TILE * CV * 2; i += PS_THREADS) reinterpret_cast<float4*>(gt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // this thread's pooled chunks (PT_POOLED^2 * CV of them, a few per thread) stay in registers across the four passes
+  constexpr int MAXP = (PT_POOLED * PT_POOLED * 8 + PS_THREADS - 1) / PS_THREADS;      // C <= 64
+  float d[MAXP][8];
+  int tgt[MAXP][8];                                           // LDS float index of the target, or -1; class in bits 30..31 is kept apart
+  unsigned cls[MAXP];                                         // 2 bits per channel
+#pragma unroll
+  for (int q = 0; q < MAXP; ++q) {
+    const int i = threadIdx.x + q * PS_THREADS;
+    cls[q] = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { tgt[q][j] = -1; d[q][j] = 0.f; }
+    if (i >= PT_POOLED * PT_POOLED * CV) continue;
+    const int cv = i % CV, pp = i / CV;
+    const int ho = ho0 + pp / PT_POOLED, wo = wo0 + pp % PT_POOLED;
+    if (ho >= Ho || wo >= Wo) continue;
+    const size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * 8;
+    uint4 g = ld16(dout + o);
+    const uint2 am = *reinterpret_cast<const uint2*>(argmax + o);
+    if (relu) {
+      const uint4 ov = ld16(out + o);
+      const unsigned ow[4] = {ov.x, ov.y, ov.z, ov.w};
+      unsigned gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned lo = ow[k] & 0xffffu, hi = ow[k] >> 16;
+        gw[k] = ((lo != 0u && lo < 0x8000u) ? (gw[k] & 0xffffu) : 0u) | ((hi != 0u && hi < 0x8000u) ? (gw[k] & 0xffff0000u) : 0u);
+      }
+      g = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+    }
+    unpack_bf8(g, d[q]);
+    const int hb = 2 * ho - pt - h0, wb = 2 * wo - pl - w0;     // tile-local position of the window's top-left tap
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int code = (int)((j < 4 ? (am.x >> (8 * j)) : (am.y >> (8 * (j - 4)))) & 0xffu);
+      const int dh = (code * 11) >> 5, dw = code - 3 * dh;      // code = 3 dh + dw, code < 9
+      const int hl = hb + dh, wl = wb + dw;
+      const bool ok = code < 9 && hl >= 0 && hl < PT_TILE && wl >= 0 && wl < PT_TILE;   // targets outside belong to the neighbouring tile
+      tgt[q][j] = ok ? (hl * PT_TILE + wl) * C + cv * 8 + j : -1;
+      cls[q] |= (unsigned)((dh >> 1) * 2 + (dw >> 1)) << (2 * j);
+    }
+  }
+  // the y chunks this thread applies BatchNorm to at the end are requested now, before the scatter passes (two workgroups per CU:
+  // the loads in flight per thread, not the wave count, have to cover the memory latency)
+  constexpr int MAXQ = PT_TILE * PT_TILE * 8 / PS_THREADS;    // C <= 64
+  uint4 yv[MAXQ];
+  size_t oo[MAXQ];
+  bool okq[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int i = threadIdx.x + q * PS_THREADS;
+    const int cv = i % CV, pix = i / CV;
+    const int h = h0 + pix / PT_TILE, w = w0 + pix % PT_TILE;
+    okq[q] = i < PT_TILE * PT_TILE * CV && h < H && w < W;
+    oo[q] = ((size_t)(n * H + h) * W + w) * C + cv * 8;
+    yv[q] = okq[q] ? ld16(y + oo[q]) : make_uint4(0u, 0u, 0u, 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    __syncthreads();                                          // the zero fill / the previous class is complete
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (tgt[q][j] >= 0 && ((cls[q] >> (2 * j)) & 3u) == (unsigned)k) gt[tgt[q][j]] += d[q][j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    if (!okq[q]) continue;
+    const int i = threadIdx.x + q * PS_THREADS;
+    const int cv = i % CV, pix = i / CV;
+    const int c = cv * 8;
+    const float4 ga = *reinterpret_cast<const float4*>(gt + (size_t)pix * C + c), gb = *reinterpret_cast<const float4*>(gt + (size_t)pix * C + c + 4);
+    const float g[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+    float v[8], r[8];
+    unpack_bf8(yv[q], v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a1[c + j] * (g[j] - k1[c + j] - (v[j] - mean[c + j]) * rstd[c + j] * k2[c + j]);
+    st16(dy + oo[q], pack_bf8(r));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // BatchNorm(+ReLU, + residual / second BN branch) backward in ONE launch: reduce, finalize and apply of the three-kernel path above.
 // ------------------------------------------------------------------------------------------------------------------
@@ -880,6 +985,7 @@ inline int reduce_grid(int M, int C) {
 }  // namespace
 
 // ---- host side of the fused backward
+int g_pool_scatter = 1;         // "pool_scatter": 1 = scatter form of the stem's pooled backward apply (C <= 64), 0 = gather form
 int g_fused_min_chunks = 3;
 int g_fused_small_chunks = 0;   // "bn_fused_small_grid": workgroups of the small-tensor launch; 0 = small tensors use the three-kernel path
 inline int fused_grid() {
@@ -1155,6 +1261,13 @@ extern "C" int yolo_bn_pool_bwd_apply(const void* dout, const void* out, const u
   const size_t pool_lds = (size_t)PT_POOLED * PT_POOLED * (C / 8) * 24;
   if (a1 && pad_t >= 0 && pad_t <= 1 && pad_l >= 0 && pad_l <= 1 && pool_lds <= 64 * 1024) {
     const int tiles_h = (H + PT_TILE - 1) / PT_TILE, tiles_w = (W + PT_TILE - 1) / PT_TILE;
+    if (g_pool_scatter && C <= 64) {
+      hipLaunchKernelGGL(bn_pool_bwd_apply_scatter_kernel, dim3(N * tiles_h * tiles_w), dim3(PS_THREADS), (size_t)PT_TILE * PT_TILE * C * 4,
+                         (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)out, argmax, relu, (const bf16_t*)y, a1, mean, rstd, k1, k2,
+                         (bf16_t*)dy, H, W, C, Ho, Wo, pad_t, pad_l, tiles_w, tiles_h);
+      YOLO_LAUNCH_CHECK();
+      return YOLO_OK;
+    }
     hipLaunchKernelGGL(bn_pool_bwd_apply_tiled_kernel, dim3(N * tiles_h * tiles_w), dim3(EW_THREADS), pool_lds, (hipStream_t)stream,
                        (const bf16_t*)dout, (const bf16_t*)out, argmax, relu, (const bf16_t*)y, a1, mean, rstd, k1, k2, (bf16_t*)dy, H, W, C,
                        Ho, Wo, pad_t, pad_l, tiles_w, tiles_h);
