@@ -216,6 +216,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(model.loss_value.item())
+    model.check_device_protocols()           # a timed-out grid barrier would make the run invalid: fail loudly
     if not np.isfinite(final_loss):
         raise SystemExit('non-finite loss %r' % final_loss)
 

@@ -170,6 +170,16 @@ class YOLOv3Model(object):
             else:
                 gb.replay()
 
+    def check_device_protocols(self):
+        """raise if a bounded device-side wait expired (the single-launch BatchNorm backward's grid barrier): results since the last
+        check cannot be trusted.  Synchronises the device: call it per epoch / at the end of a run, not per step."""
+        sync = getattr(self.g, 'bn_sync', None)
+        if sync is not None:
+            n = ops.bn_fused_timeouts(sync)
+            if n:
+                raise RuntimeError('%d grid-barrier time-outs in yolo_bn_act_bwd_fused: the cooperative grid was not resident '
+                                   '(another process on the GPU?); rerun with fused_bn_bwd = False' % n)
+
     def train_on_batch(self, images, labels):
         self.stage_batch(images, labels)
         self.run_step()

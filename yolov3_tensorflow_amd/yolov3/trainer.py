@@ -93,6 +93,7 @@ class YOLOv3Trainer(object):
                 images, labels = next(it)
                 losses.append(self.model.train_on_batch(images, labels))
             epoch_loss = float(np.mean(losses))                              # keras reports the running mean over the epoch
+            self.model.check_device_protocols()
             history['loss'].append(epoch_loss)
             history['lr'].append(lr)
             if is_main:
