@@ -77,3 +77,38 @@ def test_config1_train_steps_and_box_indices():
             np.testing.assert_array_equal(idx_gpu_host, idx_ref)
             np.testing.assert_array_equal(idx_gpu_dev, idx_ref)
             np.testing.assert_array_equal(dec_gpu[h][4][n].reshape(-1)[idx_ref], d_ref[n][..., 5:].argmax(-1).reshape(-1)[idx_ref])
+
+
+def test_config1_training_converges_on_the_sample_set():
+    """the whole loop (loss, backward, RAdam + L2) learns: epochs over the reference's 20 sample images with the reference's schedule
+    compressed -- its first-epoch rate 1e-5 while RAdam is in its un-adapted momentum branch (rho_t < 5: the update is -lr * m, which at
+    the plateau rate 1e-3 and the initial gradient scale explodes within two steps, here as in the reference; configs.py:16-17 starts at
+    1e-5 for that reason), then the plateau rate 1e-3 -- bring the epoch loss down steadily (below 60 % of the first epoch after 12 epochs = 60
+    steps) and keep it finite"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from yolov3_tensorflow_amd.configs import FLAGS
+    from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
+    from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
+    from yolov3_tensorflow_amd.utils.radam import RAdam
+    images, labels = load_fixture()
+    H = W = 320
+    N, Cn = 4, 13
+    anchors, lw = FLAGS.anchor_boxes, FLAGS.loss_weights
+    chans = [len(a) * (5 + Cn) for a in anchors]
+    grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+    model = YOLOv3Detector('resnet-18').build((H, W, 3), chans, FLAGS.head_names, batch_size=N)
+    loss = YOLOv3Loss(grids, Cn, anchors, FLAGS.iou_thresh, lw, rectified_coord_num=FLAGS.rectified_coord_num,
+                      rectified_loss_weight=FLAGS.rectified_loss_weight)
+    opt = RAdam(lr=1e-3)
+    model.compile(optimizer=opt, loss=loss.loss)
+    epochs = []
+    for epoch in range(12):
+        opt.lr = 1e-5 if epoch < 2 else 1e-3             # 10 steps at the warm-up rate: rho_t >= 5 from step 6 on
+        vals = [model.train_on_batch(images[i:i + N], labels[i:i + N]) for i in range(0, 20, N)]
+        assert all(np.isfinite(v) for v in vals), vals
+        epochs.append(float(np.mean(vals)))
+    print('epoch losses', [round(v, 2) for v in epochs])
+    assert epochs[-1] < 0.6 * epochs[0], epochs
+    assert sum(b < a for a, b in zip(epochs, epochs[1:])) >= len(epochs) - 3, epochs       # (almost) monotone
+    model.check_device_protocols()
