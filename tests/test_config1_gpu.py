@@ -79,7 +79,8 @@ def test_config1_train_steps_and_box_indices():
             np.testing.assert_array_equal(dec_gpu[h][4][n].reshape(-1)[idx_ref], d_ref[n][..., 5:].argmax(-1).reshape(-1)[idx_ref])
 
 
-def test_config1_training_converges_on_the_sample_set():
+@pytest.mark.parametrize('dtype', ['bfloat16', 'float16'])
+def test_config1_training_converges_on_the_sample_set(dtype):
     """the whole loop (loss, backward, RAdam + L2) learns: epochs over the reference's 20 sample images with the reference's schedule
     compressed -- its first-epoch rate 1e-5 while RAdam is in its un-adapted momentum branch (rho_t < 5: the update is -lr * m, which at
     the plateau rate 1e-3 and the initial gradient scale explodes within two steps, here as in the reference; configs.py:16-17 starts at
@@ -91,17 +92,26 @@ def test_config1_training_converges_on_the_sample_set():
     from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
     from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
     from yolov3_tensorflow_amd.utils.radam import RAdam
+    from yolov3_tensorflow_amd import backend
     images, labels = load_fixture()
     H = W = 320
     N, Cn = 4, 13
     anchors, lw = FLAGS.anchor_boxes, FLAGS.loss_weights
     chans = [len(a) * (5 + Cn) for a in anchors]
     grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
-    model = YOLOv3Detector('resnet-18').build((H, W, 3), chans, FLAGS.head_names, batch_size=N)
-    loss = YOLOv3Loss(grids, Cn, anchors, FLAGS.iou_thresh, lw, rectified_coord_num=FLAGS.rectified_coord_num,
-                      rectified_loss_weight=FLAGS.rectified_loss_weight)
-    opt = RAdam(lr=1e-3)
-    model.compile(optimizer=opt, loss=loss.loss)
+    backend.set_compute_dtype(dtype)                   # float16: the fp16 library build with its static loss scale
+    try:
+        model = YOLOv3Detector('resnet-18').build((H, W, 3), chans, FLAGS.head_names, batch_size=N)
+        loss = YOLOv3Loss(grids, Cn, anchors, FLAGS.iou_thresh, lw, rectified_coord_num=FLAGS.rectified_coord_num,
+                          rectified_loss_weight=FLAGS.rectified_loss_weight)
+        opt = RAdam(lr=1e-3)
+        model.compile(optimizer=opt, loss=loss.loss)
+        _converge(model, opt, images, labels, N)
+    finally:
+        backend.set_compute_dtype('bfloat16')
+
+
+def _converge(model, opt, images, labels, N):
     epochs = []
     for epoch in range(12):
         opt.lr = 1e-5 if epoch < 2 else 1e-3             # 10 steps at the warm-up rate: rho_t >= 5 from step 6 on
