@@ -78,6 +78,7 @@ FLAGS.image_root_path = None
 FLAGS.gpu_mode = 'gpu'
 FLAGS.gpu_num = 1
 FLAGS.visible_gpu = '0'
+FLAGS.full_state_resume = False   # not in the reference: also checkpoint / restore the RAdam moments, step counter, rectified-image counter, epoch
 
 
 def refresh_derived():

@@ -287,21 +287,55 @@ class YOLOv3Model(object):
             self.g.refresh_dgrad_weights()
             torch.cuda.synchronize(self.device)
 
-    def save_weights(self, path):
+    def save_weights(self, path, full_state=False, epoch=None):
         """weights-only checkpoint under the reference's file stem (trainer.py:90-91).  The TF SSTable byte format cannot be
         produced without TensorFlow: variables are stored by Keras name in ``<path>.npz`` and a TF-style
-        ``checkpoint`` pointer file names the latest stem."""
+        ``checkpoint`` pointer file names the latest stem.
+        ``full_state`` (opt-in; the reference restores weights only, so the RAdam moments, its step counter, the rectified-loss image
+        counter and the epoch -- hence the learning-rate schedule -- restart) additionally writes
+        ``<path>.state.npz`` with exactly those, in the flat device layout of this build."""
         d = os.path.dirname(path)
         if d and not os.path.exists(d):
             os.makedirs(d)
         np.savez(path + '.npz', **self.get_weights())
+        if full_state:
+            ps, opt = self.g.ps, self.optimizer
+            state = {'layout_n': np.int64(ps.n), 'm': ps.m.detach().cpu().numpy(), 'v': ps.v.detach().cpu().numpy(),
+                     'master': ps.flat.detach().cpu().numpy(),      # float32 master weights in device layout: the resume is bit-exact
+                     'iterations': np.int64(opt.iterations if opt is not None else 0), 'epoch': np.int64(-1 if epoch is None else epoch),
+                     'current_num': np.int64(int(self.loss_obj.current_num.item()) if self.loss_obj is not None else 0)}
+            if opt is not None and opt.vhat is not None:
+                state['vhat'] = opt.vhat.detach().cpu().numpy()
+            np.savez(path + '.state.npz', **state)
         with open(os.path.join(d, 'checkpoint'), 'w') as f:
             f.write('model_checkpoint_path: %s\n' % json.dumps(os.path.basename(path)))
 
-    def load_weights(self, path):
-        p = path if path.endswith('.npz') else path + '.npz'
-        with np.load(p, allow_pickle=False) as z:
+    def load_weights(self, path, full_state=False):
+        """-> the epoch stored with a full-state checkpoint (or None)"""
+        stem = path[:-4] if path.endswith('.npz') else path
+        with np.load(stem + '.npz', allow_pickle=False) as z:
             self.set_weights({k: z[k] for k in z.files})
+        if not full_state or not os.path.exists(stem + '.state.npz'):
+            return None
+        if self.optimizer is None or self.loss_obj is None:
+            raise RuntimeError('compile(optimizer, loss) before restoring a full-state checkpoint')
+        with np.load(stem + '.state.npz', allow_pickle=False) as z:
+            ps, opt = self.g.ps, self.optimizer
+            if int(z['layout_n']) != ps.n:
+                raise ValueError('optimizer state was saved for a different model layout (%d slots, this model has %d)' % (int(z['layout_n']), ps.n))
+            with torch.cuda.device(self.device):
+                ps.m.copy_(torch.as_tensor(z['m']))
+                ps.v.copy_(torch.as_tensor(z['v']))
+                ps.flat.copy_(torch.as_tensor(z['master']))
+                ops.cast_f32_to_bf16(ps.flat, ps.bf16, ps.n)
+                self.g.refresh_dgrad_weights()
+                opt._iterations.fill_(int(z['iterations']))
+                if 'vhat' in z.files and opt.vhat is not None:
+                    opt.vhat.copy_(torch.as_tensor(z['vhat']))
+                self.loss_obj.current_num.fill_(int(z['current_num']))
+                torch.cuda.synchronize(self.device)
+            epoch = int(z['epoch'])
+        return epoch if epoch >= 0 else None
 
 
 def latest_checkpoint(directory):

@@ -38,12 +38,14 @@ class YOLOv3Trainer(object):
             self.checkpoint_path = 'models/'
         if os.path.isfile(self.checkpoint_path) or os.path.isfile(self.checkpoint_path + '.npz'):
             self.model.load_weights(self.checkpoint_path)
+            self._resumed_from = self.checkpoint_path
             logging.info('weights loaded')
             self.checkpoint_path = os.path.dirname(self.checkpoint_path)
         if os.path.isdir(self.checkpoint_path):
             latest = model_lib.latest_checkpoint(self.checkpoint_path)
             if latest is not None:
                 self.model.load_weights(latest)
+                self._resumed_from = latest
                 logging.info('weights loaded: %s', latest)
         else:
             self.checkpoint_path = os.path.dirname(self.checkpoint_path)
@@ -63,6 +65,14 @@ class YOLOv3Trainer(object):
         self.loss_function = self.loss_object.loss
         self.optimizer = optimizer
         self.model.compile(optimizer=optimizer, loss=self.loss_function)
+        # opt-in (not in the reference, which resumes with weights only -- SURVEY.md appendix B): restore the optimizer moments, its step
+        # counter, the rectified-loss image counter and the epoch, so that the schedule continues instead of restarting
+        self.start_epoch = 0
+        if FLAGS.get('full_state_resume') and getattr(self, '_resumed_from', None):
+            ep = self.model.load_weights(self._resumed_from, full_state=True)
+            if ep is not None:
+                self.start_epoch = ep + 1
+                logging.info('full training state restored: continuing with epoch %d', self.start_epoch + 1)
         self.epoch = FLAGS.epoch
         self.ckpt_period = FLAGS.ckpt_period
         self.stop_patience, self.stop_min_delta = FLAGS.stop_patience, FLAGS.stop_min_delta
@@ -83,7 +93,7 @@ class YOLOv3Trainer(object):
         for cb in callbacks:
             cb.set_model(self.model, self.loss_object)
         self.log_callback.on_train_begin(self.epoch, train_steps)
-        for epoch in range(self.epoch):
+        for epoch in range(self.start_epoch, self.epoch):
             lr = float(self.lr_func(epoch))                                 # LearningRateScheduler (reference :94)
             self.optimizer.lr = lr
             if is_main:
@@ -102,7 +112,7 @@ class YOLOv3Trainer(object):
                 self.log_callback.on_epoch_end(epoch, logs)                  # DetailLossLogger (reference :95)
                 if (epoch + 1) % self.ckpt_period == 0:                      # ModelCheckpoint(period) (reference :90-91)
                     path = self.checkpoint_path.format(epoch=epoch + 1, loss=epoch_loss)
-                    self.model.save_weights(path)
+                    self.model.save_weights(path, full_state=bool(FLAGS.get('full_state_resume')), epoch=epoch)
                     logging.info('saved %s', path)
             if best - epoch_loss > self.stop_min_delta:                      # EarlyStopping(monitor='loss') (reference :92-93)
                 best, wait = epoch_loss, 0
