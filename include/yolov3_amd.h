@@ -282,10 +282,12 @@ int yolo_radam_schedule(float* sched, int64_t* iterations, float beta1, float be
 int yolo_radam_l2_blocks(int64_t n);   /* length of l2_partial */
 /* n (multiple of 256) elements; l2_table[n/256] = lambda of each 256-element chunk; grads are multiplied by grad_scale and
  * zeroed afterwards if zero_grad; params_bf16 (may be NULL) receives the bf16 copy; vhat (may be NULL) enables AMSGrad;
- * l2_partial (may be NULL) receives per-workgroup sums of lambda*p^2 at the pre-update weights. */
+ * l2_partial (may be NULL) receives per-workgroup sums of lambda*p^2 at the pre-update weights; nonfinite (device int32, may be NULL):
+ * gradient elements that are inf / NaN (fp16 overflow) are not applied (treated as 0) and *nonfinite is incremented once per wave
+ * that saw one -- the caller checks it and lowers the loss scale / fails loudly. */
 int yolo_radam_l2_step(float* params, float* grads, float* m, float* v, float* vhat, void* params_bf16, const float* l2_table,
                        int64_t n, const float* sched, float beta1, float beta2, float eps, float grad_scale, int zero_grad,
-                       float* l2_partial, void* stream);
+                       float* l2_partial, int* nonfinite, void* stream);
 int yolo_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 int yolo_sum_partials(const float* partial, int n, const float* add, float* out, void* stream);
 

@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu():
     assert b'Cin' in lib.yolo_last_error()
     p = _lib.ConvProblem(1, 8, 8, 64, 0, 100, 3, 3, 1, 1, 1, 8, 8)     # Cout not padded
     assert lib.yolo_conv2d_fwd(ctypes.byref(p), None, None, None, None, None, 0, None, None, None) == -1
-    assert lib.yolo_radam_l2_step(None, None, None, None, None, None, None, 256, None, 0.9, 0.999, 1e-8, 1.0, 1, None, None) == -1
+    assert lib.yolo_radam_l2_step(None, None, None, None, None, None, None, 256, None, 0.9, 0.999, 1e-8, 1.0, 1, None, None, None) == -1
     assert lib.yolo_reduce_rows(100, 24) == -1       # 256 % (C/8) != 0
     assert lib.yolo_reduce_rows(100, 64) > 0
 

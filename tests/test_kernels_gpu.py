@@ -741,6 +741,41 @@ def test_radam_l2_step_vs_oracle(dev):
         assert torch.equal(pb.cpu(), p.cpu().to(ACT()))
 
 
+def test_radam_skips_and_counts_nonfinite_gradients(dev):
+    """an inf / NaN gradient element (fp16 overflow in the backward pass) is not applied -- that element takes the step a zero gradient
+    would give -- and the wave is counted; every other element updates as usual; without the counter argument the old behaviour remains"""
+    from yolov3_tensorflow_amd import ops
+    n = 1024
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    grad = torch.randn(n, generator=g)
+    bad = grad.clone()
+    bad[5], bad[300], bad[301] = float('inf'), float('nan'), float('-inf')           # waves 0 and 4 (64 lanes x 4 elements per wave trip)
+    clean = grad.clone()
+    clean[5] = clean[300] = clean[301] = 0.0
+    lam = torch.zeros(n // 256)
+
+    def step(gr, counter):
+        p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        sched = torch.tensor([1e-3, 0, 0, 0], device=dev)
+        it = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops.radam_schedule(sched, it, 0.9, 0.999, 0.0, 1.0)
+        ops.radam_l2_step(p, gr.clone().to(dev), m, v, lam.to(dev), n, sched, 0.9, 0.999, 1e-8, 1.0, True, nonfinite=counter)
+        torch.cuda.synchronize()
+        return p.cpu(), m.cpu()
+
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    p_bad, m_bad = step(bad, cnt)
+    p_ref, m_ref = step(clean, None)
+    assert int(cnt.item()) == 2
+    assert torch.equal(p_bad, p_ref) and torch.equal(m_bad, m_ref) and torch.isfinite(p_bad).all()
+    cnt.zero_()
+    step(grad, cnt)
+    assert int(cnt.item()) == 0
+    p_unguarded, _ = step(bad, None)
+    assert not torch.isfinite(p_unguarded).all()
+
+
 # ---- the fp16 build (libyolov3_amd_fp16.so: same sources, IEEE half elements, f16 MFMA) through the same checks ----
 FP16_CONV = [CONV_CASES[i] for i in (0, 1, 2, len(CONV_CASES) - 5, len(CONV_CASES) - 4, len(CONV_CASES) - 2, len(CONV_CASES) - 1)]
 

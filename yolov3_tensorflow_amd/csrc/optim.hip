@@ -43,10 +43,11 @@ __global__ __launch_bounds__(OPT_THREADS) void radam_l2_kernel(float* __restrict
                                                                float* __restrict__ v, float* __restrict__ vhat, bf16_t* __restrict__ pb,
                                                                const float* __restrict__ l2_table, size_t n4, const float* __restrict__ sched,
                                                                float beta1, float beta2, float eps, float grad_scale, int zero_grad,
-                                                               float* __restrict__ l2_partial) {
+                                                               float* __restrict__ l2_partial, int* __restrict__ nonfinite) {
   const float lr_t = sched[1];
   const bool adaptive = sched[3] != 0.f;
   float l2acc = 0.f;
+  bool bad = false;
   for (size_t i = (size_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * OPT_THREADS) {
     const float lam = l2_table[(i * 4) / OPT_CHUNK];
     float4 P = reinterpret_cast<float4*>(p)[i];
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(OPT_THREADS) void radam_l2_kernel(float* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       l2acc += lam * pp[j] * pp[j];
+      if (nonfinite && !__builtin_isfinite(gg[j])) { gg[j] = 0.f; bad = true; }   // an overflowed (fp16) / NaN gradient element: not applied, counted
       const float gr = gg[j] * grad_scale + 2.f * lam * pp[j];
       mm[j] = beta1 * mm[j] + (1.f - beta1) * gr;                    // radam.py:88
       vv[j] = beta2 * vv[j] + (1.f - beta2) * (gr * gr);             // radam.py:89
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(OPT_THREADS) void radam_l2_kernel(float* __restrict
       reinterpret_cast<uint2*>(pb)[i] = o;
     }
   }
+  if (nonfinite && __any(bad) && (threadIdx.x & 63) == 0) atomicAdd(nonfinite, 1);
   __shared__ float red[OPT_THREADS / 64];
   const float s = wave_sum(l2acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -128,12 +131,12 @@ extern "C" int yolo_radam_l2_blocks(int64_t n) { return n > 0 && n % OPT_CHUNK =
 
 extern "C" int yolo_radam_l2_step(float* params, float* grads, float* m, float* v, float* vhat, void* params_bf16, const float* l2_table,
                                   int64_t n, const float* sched, float beta1, float beta2, float eps, float grad_scale, int zero_grad,
-                                  float* l2_partial, void* stream) {
+                                  float* l2_partial, int* nonfinite, void* stream) {
   YOLO_CHECK_ARG(params && grads && m && v && l2_table && sched, "null pointer");
   YOLO_CHECK_ARG(n > 0 && n % OPT_CHUNK == 0, "n must be a positive multiple of 256 (slots are padded)");
   const size_t n4 = (size_t)n / 4;
   hipLaunchKernelGGL(radam_l2_kernel, dim3(opt_grid(n4)), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grads, m, v, vhat,
-                     (bf16_t*)params_bf16, l2_table, n4, sched, beta1, beta2, eps, grad_scale, zero_grad, l2_partial);
+                     (bf16_t*)params_bf16, l2_table, n4, sched, beta1, beta2, eps, grad_scale, zero_grad, l2_partial, nonfinite);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

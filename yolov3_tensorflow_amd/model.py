@@ -179,6 +179,16 @@ class YOLOv3Model(object):
             if n:
                 raise RuntimeError('%d grid-barrier time-outs in yolo_bn_act_bwd_fused: the cooperative grid was not resident '
                                    '(another process on the GPU?); rerun with fused_bn_bwd = False' % n)
+        nf = getattr(self.optimizer, 'nonfinite', None)
+        if nf is not None:
+            n = int(nf.item())
+            if n:
+                nf.zero_()
+                from . import backend
+                hint = (' (float16: lower the loss scale, backend.set_loss_scale(%g))' % (backend.loss_scale() / 4)
+                        if backend.compute_dtype() == 'float16' else '')
+                raise FloatingPointError('non-finite gradient elements reached the optimizer in %d waves since the last check; they were '
+                                         'not applied%s' % (n, hint))
 
     def train_on_batch(self, images, labels):
         self.stage_batch(images, labels)

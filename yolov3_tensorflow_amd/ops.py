@@ -335,9 +335,9 @@ def radam_l2_blocks(n):
 
 
 def radam_l2_step(params, grads, m, v, l2_table, n, sched, beta1, beta2, eps, grad_scale=1.0, zero_grad=True, params_bf16=None,
-                  vhat=None, l2_partial=None):
+                  vhat=None, l2_partial=None, nonfinite=None):
     check(_lib.load().yolo_radam_l2_step(_p(params), _p(grads), _p(m), _p(v), _p(vhat), _p(params_bf16), _p(l2_table), n, _p(sched),
-                                         beta1, beta2, eps, grad_scale, int(zero_grad), _p(l2_partial), _stream()), 'yolo_radam_l2_step')
+                                         beta1, beta2, eps, grad_scale, int(zero_grad), _p(l2_partial), _p(nonfinite), _stream()), 'yolo_radam_l2_step')
 
 
 def cast_f32_to_bf16(x, y, n):

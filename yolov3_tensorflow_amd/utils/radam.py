@@ -47,13 +47,14 @@ class RAdam(object):
             self._iterations = torch.zeros(1, dtype=torch.int64, device=dev)
             self.vhat = torch.zeros(ps.n, device=dev) if self.amsgrad else None
             self.l2_partial = torch.zeros(ops.radam_l2_blocks(ps.n), device=dev)
+            self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)      # waves that met an inf / NaN gradient element
 
     def launch(self, model):
         ps = model.g.ps
         ops.radam_schedule(self.sched, self._iterations, self.beta_1, self.beta_2, self.initial_decay, self.warmup_coef)
         ops.radam_l2_step(ps.flat, ps.grad, ps.m, ps.v, ps.l2_table, ps.n, self.sched, self.beta_1, self.beta_2, self.epsilon,
                           grad_scale=1.0 / (model.world_size * backend.loss_scale()), zero_grad=True, params_bf16=ps.bf16, vhat=self.vhat,
-                          l2_partial=self.l2_partial)
+                          l2_partial=self.l2_partial, nonfinite=self.nonfinite)
         # reported loss = YOLOv3 loss + sum of L2 regularisers (what keras' compiled loss contains)
         ops.sum_partials(self.l2_partial, self.l2_partial.numel(), None, model.l2_value)
         ops.sum_partials(self.l2_partial, self.l2_partial.numel(), model.loss_obj.total, model.loss_value)
