@@ -14,11 +14,20 @@ import numpy as np
 from yolov3_tensorflow_amd.dataset.dataset_util import DatasetUtil
 
 
+class _Slot(object):
+    """one in-flight batch: pinned staging bytes + descriptor block, their device twins, and the event after which they may be reused"""
+
+    def __init__(self):
+        self.stage = self.dev = self.desc_host = self.desc_dev = self.event = None
+        self.descs = self.total = self.views = None
+
+
 class DeviceImagePipeline(object):
     """one batch of decoded uint8 RGB images (any sizes) -> float32 (N, H, W, 3) BGR [0, 1] on the GPU (and, optionally, the packed
-    bf16 conv input).  Owns a pinned staging buffer so the upload of batch k+1 can overlap the kernels of batch k."""
+    bf16 conv input).  Batches travel through a ring of slots (pinned staging buffer + descriptor block + device twins): decode threads
+    write their pixels straight into the pinned buffer of a slot while the GPU still works on the previous ones."""
 
-    def __init__(self, batch_size, image_size, device=None, max_pixels_per_image=4096 * 4096):
+    def __init__(self, batch_size, image_size, device=None, max_pixels_per_image=4096 * 4096, slots=4):
         import torch
         from yolov3_tensorflow_amd import ops, _lib
         if not torch.cuda.is_available():
@@ -27,11 +36,9 @@ class DeviceImagePipeline(object):
         self.N, (self.H, self.W) = int(batch_size), (int(image_size[0]), int(image_size[1]))
         self.device = torch.device('cuda:%d' % torch.cuda.current_device()) if device is None else torch.device(device)
         self.max_pixels = int(max_pixels_per_image)
-        self._stage = None
-        self._dev = None
         self.workspace = torch.empty(ops.letterbox_workspace_bytes(self.N), dtype=torch.uint8, device=self.device)
-        self._desc_host = torch.empty(self.N * ctypes.sizeof(_lib.ImageDesc), dtype=torch.uint8).pin_memory()
-        self._desc_dev = torch.empty_like(self._desc_host, device=self.device)
+        self._slots = [_Slot() for _ in range(max(2, int(slots)))]
+        self._next = 0
 
     @staticmethod
     def geometry(h, w, H, W):
@@ -40,17 +47,20 @@ class DeviceImagePipeline(object):
         rh, rw = float(h) / ratio, float(w) / ratio
         return int(math.floor(rh)), int(math.floor(rw)), max(0, int(math.floor((H - rh) / 2))), max(0, int(math.floor((W - rw) / 2)))
 
-    def __call__(self, images_rgb_u8, draws=None, out_f32=True, out_bf16x8=None):
-        """images_rgb_u8: list of N uint8 (h, w, 3) arrays; draws: list of DatasetUtil.draw() dicts (None = no augmentation)"""
+    def acquire(self, sizes_hw):
+        """reserve the next slot for N images of the given decoded sizes (any thread): -> slot with ``views[n]`` = uint8 (h, w, 3) windows
+        of its pinned buffer to decode / copy into.  Blocks only if the GPU has not finished with that slot's previous batch."""
         torch = self.torch
-        if len(images_rgb_u8) != self.N:
-            raise ValueError('expected %d images, got %d' % (self.N, len(images_rgb_u8)))
+        if len(sizes_hw) != self.N:
+            raise ValueError('expected %d images, got %d' % (self.N, len(sizes_hw)))
+        slot = self._slots[self._next]
+        self._next = (self._next + 1) % len(self._slots)
+        if slot.event is not None:
+            slot.event.synchronize()
         total = 0
         descs = (self.lib.ImageDesc * self.N)()
-        for n, im in enumerate(images_rgb_u8):
-            if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
-                raise ValueError('image %d must be uint8 (h, w, 3), got %s %s' % (n, im.dtype, im.shape))
-            h, w = im.shape[:2]
+        for n, (h, w) in enumerate(sizes_hw):
+            h, w = int(h), int(w)
             if h * w > self.max_pixels or h < 1 or w < 1:
                 raise ValueError('image %d has unsupported size %dx%d' % (n, h, w))
             nh, nw, top, left = self.geometry(h, w, self.H, self.W)
@@ -58,25 +68,46 @@ class DeviceImagePipeline(object):
                 raise ValueError('image %d (%dx%d) collapses to nothing at %dx%d' % (n, h, w, self.H, self.W))
             d = descs[n]
             d.offset, d.h, d.w, d.nh, d.nw, d.top, d.left = total, h, w, nh, nw, top, left
-            for k, v in (draws[n] if draws is not None else DatasetUtil.NO_AUGMENT).items():
-                setattr(d, k, v)
             total += (h * w * 3 + 15) // 16 * 16
-        if self._stage is None or self._stage.numel() < total:
-            self._stage = torch.empty(int(total * 1.25), dtype=torch.uint8).pin_memory()
-            self._dev = torch.empty(self._stage.numel(), dtype=torch.uint8, device=self.device)
-        else:
-            torch.cuda.current_stream(self.device).synchronize()       # the previous batch's upload has left the staging buffer
-        stage = self._stage.numpy()
-        for n, im in enumerate(images_rgb_u8):
-            o = descs[n].offset
-            stage[o:o + im.size] = np.ascontiguousarray(im).reshape(-1)
-        ctypes.memmove(self._desc_host.data_ptr(), ctypes.addressof(descs), ctypes.sizeof(descs))
-        self._dev[:total].copy_(self._stage[:total], non_blocking=True)
-        self._desc_dev.copy_(self._desc_host, non_blocking=True)
+        if slot.stage is None or slot.stage.numel() < total:
+            with torch.cuda.device(self.device):
+                slot.stage = torch.empty(int(total * 1.25), dtype=torch.uint8).pin_memory()
+                slot.dev = torch.empty(slot.stage.numel(), dtype=torch.uint8, device=self.device)
+                if slot.desc_host is None:
+                    slot.desc_host = torch.empty(self.N * ctypes.sizeof(self.lib.ImageDesc), dtype=torch.uint8).pin_memory()
+                    slot.desc_dev = torch.empty_like(slot.desc_host, device=self.device)
+        stage = slot.stage.numpy()
+        slot.descs, slot.total = descs, total
+        slot.views = [stage[descs[n].offset:descs[n].offset + descs[n].h * descs[n].w * 3].reshape(descs[n].h, descs[n].w, 3)
+                      for n in range(self.N)]
+        return slot
+
+    def run(self, slot, draws=None, out_f32=True, out_bf16x8=None):
+        """upload the filled slot and launch the kernel on the current stream (consumer thread)"""
+        torch = self.torch
+        for n in range(self.N):
+            for k, v in (draws[n] if draws is not None else DatasetUtil.NO_AUGMENT).items():
+                setattr(slot.descs[n], k, v)
+        ctypes.memmove(slot.desc_host.data_ptr(), ctypes.addressof(slot.descs), ctypes.sizeof(slot.descs))
+        slot.dev[:slot.total].copy_(slot.stage[:slot.total], non_blocking=True)
+        slot.desc_dev.copy_(slot.desc_host, non_blocking=True)
         out = torch.empty(self.N, self.H, self.W, 3, device=self.device) if out_f32 else None
-        self.ops.letterbox_augment(self._dev, self._desc_dev, self.N, self.H, self.W, draws is not None, self.workspace, out_f32=out,
+        self.ops.letterbox_augment(slot.dev, slot.desc_dev, self.N, self.H, self.W, draws is not None, self.workspace, out_f32=out,
                                    out_bf16x8=out_bf16x8)
+        if slot.event is None:
+            slot.event = torch.cuda.Event()
+        slot.event.record(torch.cuda.current_stream(self.device))
         return out
+
+    def __call__(self, images_rgb_u8, draws=None, out_f32=True, out_bf16x8=None):
+        """images_rgb_u8: list of N uint8 (h, w, 3) arrays; draws: list of DatasetUtil.draw() dicts (None = no augmentation)"""
+        for n, im in enumerate(images_rgb_u8):
+            if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                raise ValueError('image %d must be uint8 (h, w, 3), got %s %s' % (n, im.dtype, im.shape))
+        slot = self.acquire([im.shape[:2] for im in images_rgb_u8])
+        for view, im in zip(slot.views, images_rgb_u8):
+            np.copyto(view, im)
+        return self.run(slot, draws, out_f32=out_f32, out_bf16x8=out_bf16x8)
 
 
 class FileUtil(object):
@@ -112,8 +143,15 @@ class FileUtil(object):
         return np.asarray(Image.open(path).convert('RGB'))
 
     @staticmethod
-    def host_batches(file_path, image_dir, image_size, batch_size, is_augment=True, is_test=False, seed=800):
-        """the host half of get_dataset: (decoded images, padded transformed labels (N, T*5), augmentation draws or None, paths)"""
+    def _copy_into(args):
+        np.copyto(args[0], args[1])          # releases the GIL for the whole image
+
+    @staticmethod
+    def host_batches(file_path, image_dir, image_size, batch_size, is_augment=True, is_test=False, seed=800, pool=None, pipe=None):
+        """the host half of get_dataset: (decoded images, padded transformed labels (N, T*5), augmentation draws or None, paths).
+        ``pool``: a concurrent.futures executor that decodes the images of a batch in parallel (PIL releases the GIL while decoding);
+        order, pairing and the random draws do not depend on it.  With ``pipe`` (a DeviceImagePipeline) the first element is a filled slot
+        of its staging ring instead of a list of arrays: the decode threads also copy the pixels into the pinned memory"""
         names, labels = FileUtil._parse_label_file(file_path)
         if not names:
             raise ValueError('empty label file ' + file_path)
@@ -127,24 +165,72 @@ class FileUtil(object):
                 idx = order[i:i + batch_size]
                 if len(idx) < batch_size:                            # keras fit gets full batches; pad the last test batch by wrap-around
                     idx = np.concatenate([idx, order[:batch_size - len(idx)]])
-                imgs, labs = [], -np.ones((batch_size, t_max, 5), dtype=np.float32)
+                labs = -np.ones((batch_size, t_max, 5), dtype=np.float32)
+                paths = [os.path.join(image_dir, names[j]) for j in idx]
+                mapper = pool.map if pool is not None else map
+                imgs = list(mapper(FileUtil.read_image, paths))
+                sizes = [im.shape[:2] for im in imgs]
+                if pipe is not None:                                 # into the pinned staging memory, also on the decode threads
+                    arrays, imgs = imgs, pipe.acquire(sizes)
+                    list(mapper(FileUtil._copy_into, zip(imgs.views, arrays)))
                 for k, j in enumerate(idx):
-                    im = FileUtil.read_image(os.path.join(image_dir, names[j]))
-                    lb = FileUtil.transform_label(labels[j], im.shape[:2], image_size)
-                    imgs.append(im)
+                    lb = FileUtil.transform_label(labels[j], sizes[k], image_size)
                     labs[k, :len(lb)] = lb
                 draws = [DatasetUtil.draw(rng) for _ in idx] if (is_augment and not is_test) else None
-                yield imgs, labs.reshape(batch_size, t_max * 5), draws, [os.path.join(image_dir, names[j]) for j in idx]
+                yield imgs, labs.reshape(batch_size, t_max * 5), draws, paths
             if is_test:
                 return
 
     @staticmethod
-    def get_dataset(file_path, image_dir, image_size, batch_size, is_augment=True, is_test=False, seed=800, device=None):
-        """reference :62-114"""
-        pipe = DeviceImagePipeline(batch_size, image_size, device=device)
+    def get_dataset(file_path, image_dir, image_size, batch_size, is_augment=True, is_test=False, seed=800, device=None, num_workers=None,
+                    prefetch=3):
+        """reference :62-114 (its tf.data pipeline decodes with AUTOTUNE parallelism and prefetches, :85-114).  Here ``num_workers`` threads
+        (default: the CPUs of this process, at most 8 -- Python threads stop scaling there: ~3000 images/s of 500 x 375 JPEGs on the GPU box's host,
+        tools/input_pipeline_bench.py) decode the JPEGs of a batch and a producer thread keeps ``prefetch`` decoded
+        batches ahead of the GPU; resize / normalise / augment then run in the GPU kernel on the consumer side."""
+        import concurrent.futures
+        import queue
+        import threading
+        pipe = DeviceImagePipeline(batch_size, image_size, device=device, slots=max(1, prefetch) + 3)
+        if num_workers is None:
+            num_workers = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
 
         def batches():
-            for imgs, labs, draws, paths in FileUtil.host_batches(file_path, image_dir, image_size, batch_size, is_augment, is_test, seed):
-                x = pipe(imgs, draws)
-                yield (x, labs, paths) if is_test else (x, labs)
+            pool = concurrent.futures.ThreadPoolExecutor(max_workers=num_workers) if num_workers > 1 else None
+            q = queue.Queue(maxsize=max(1, prefetch))
+            stop = threading.Event()
+            done = object()
+
+            def produce():
+                try:
+                    for item in FileUtil.host_batches(file_path, image_dir, image_size, batch_size, is_augment, is_test, seed, pool=pool,
+                                                      pipe=pipe):
+                        while not stop.is_set():
+                            try:
+                                q.put(item, timeout=0.1)
+                                break
+                            except queue.Full:
+                                continue
+                        if stop.is_set():
+                            return
+                    q.put(done)
+                except BaseException as e:            # surface decode errors on the consumer side
+                    q.put(e)
+
+            t = threading.Thread(target=produce, daemon=True)
+            t.start()
+            try:
+                while True:
+                    item = q.get()
+                    if item is done:
+                        return
+                    if isinstance(item, BaseException):
+                        raise item
+                    slot, labs, draws, paths = item
+                    x = pipe.run(slot, draws)
+                    yield (x, labs, paths) if is_test else (x, labs)
+            finally:
+                stop.set()
+                if pool is not None:
+                    pool.shutdown(wait=False)
         return batches()
