@@ -56,7 +56,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_stats_kernel(const bf16_t* __re
 // per 32 channels left a 64-channel layer's 5408 partial rows to 2 workgroups: 42 us of pure load latency per launch.)
 template <int K>
 __device__ __forceinline__ bool column_reduce(const float* const (&src)[K], int P, size_t rstride, int C, double (&tot)[K]) {
-  __shared__ double red[K][128][8];
+  __shared__ double red[K][16][8];
   const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   double s[K];
@@ -85,18 +85,29 @@ __device__ __forceinline__ bool column_reduce(const float* const (&src)[K], int 
 #pragma unroll
     for (int k = 0; k < K; ++k) s[k] = ((double)f[k][0] + (double)f[k][1]) + ((double)f[k][2] + (double)f[k][3]);
   }
+  // row-lanes of one wave (lane = 8 * (rl & 7) + cl) meet by shuffles, the 16 waves through one LDS exchange (one barrier instead of the
+  // eight of a shared-memory tree: these launches are latency, not work)
 #pragma unroll
-  for (int k = 0; k < K; ++k) red[k][rl][cl] = s[k];
-  __syncthreads();
-  for (int o = 64; o > 0; o >>= 1) {
-    if (rl < o) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) red[k][rl][cl] += red[k][rl + o][cl];
-    }
-    __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    s[k] += __shfl_xor(s[k], 8, 64);
+    s[k] += __shfl_xor(s[k], 16, 64);
+    s[k] += __shfl_xor(s[k], 32, 64);
   }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < 8) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) tot[k] = red[k][0][cl];
+    for (int k = 0; k < K; ++k) red[k][wave][lane] = s[k];
+  }
+  __syncthreads();
+  if (rl == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) t += red[k][w][cl];
+      tot[k] = t;
+    }
+  }
   return rl == 0 && c < C;
 }
 
