@@ -265,6 +265,10 @@ def test_eager_two_stream_and_bucketed_allreduce_match_serial():
                 model.overlap_wgrad = False
                 model.overlap_allreduce = False
             assert 0 < model.g.bucket_offset < model.g.ps.n
+            # three buckets by backbone stage: [stride-32 stage + heads | stride-8/16 stages | stem + stride-4 stage] partition the gradient
+            (c1_, lo1, hi1), (c2_, lo2, hi2) = model.g.buckets
+            assert hi1 is None and hi2 == lo1 and model.g.bucket_tail == lo2 and 0 < lo2 < lo1 < model.g.ps.n and c1_ < c2_
+            assert lo2 < 0.05 * model.g.ps.n and (model.g.ps.n - lo1) > 0.5 * model.g.ps.n      # the exposed tail bucket is tiny, the first one the bulk
             curve = [model.train_on_batch(images, labels) for _ in range(3)]
             results.append((curve, model.get_weights()))
     finally:

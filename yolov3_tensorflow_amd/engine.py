@@ -197,6 +197,7 @@ class Graph(object):
         self._wgrad_pending = []
         self._wgrad_cost, self.wgrad_cost_limit = 0.0, 18.0   # ... or as soon as the pending ones reach this many GFLOP (a big 3x3 layer goes alone)
         self.bucket_cut, self.bucket_offset, self.on_bucket = -1, 0, None
+        self.buckets, self.bucket_tail = [], None
 
     # ------------------------------------------------------------------------------------------------ allocation helpers
     def _buffer(self, shape, dtype=None):
@@ -395,14 +396,27 @@ class Graph(object):
         for op in reversed(self.tape):
             op.plan_backward()
             self.bwd.append(op.backward)
-        # gradient bucket for data-parallel overlap: everything created from the first stride-32 convolution on (module512 + the three
-        # heads = ~70 % of the parameters) finishes its backward first; its slice of the flat gradient is [bucket_offset, n)
-        H32 = self.input_val.shape[1] // 32
-        for i, op in enumerate(self.tape):
-            if isinstance(op, ConvOp) and op.y.shape[1] == H32:
-                self.bucket_offset = op.y.wp.offset
-                self.bucket_cut = len(self.tape) - 1 - i          # index in the reversed launch list
-                break
+        # gradient buckets for data-parallel overlap, by backbone stage (parameters are laid out in creation order, backward runs in reverse):
+        #   [first stride-32 conv, n)   module512 + the three heads, ~70 % of the parameters: complete ~40 % into the backward pass
+        #   [first stride-8 conv, that) the stride-8 / stride-16 stages
+        #   [0, first stride-8 conv)    stem + stride-4 stage (~1 % of the parameters): the only bucket whose all-reduce is exposed
+        # self.buckets = [(index in the backward launch list after which the bucket is complete, lo, hi), ...] in completion order
+        H = self.input_val.shape[1]
+        marks = []
+        for div in (32, 8):
+            for i, op in enumerate(self.tape):
+                if isinstance(op, ConvOp) and op.y.shape[1] == H // div and (not marks or op.y.wp.offset < marks[-1][1]):
+                    marks.append((len(self.tape) - 1 - i, op.y.wp.offset))
+                    break
+        self.buckets = []
+        hi = None
+        for cut, lo in marks:
+            if lo > 0:
+                self.buckets.append((cut, lo, hi))            # hi = None: up to ps.n (known after allocation)
+                hi = lo
+        self.bucket_tail = hi                                  # [0, bucket_tail) remains after the backward pass (None: everything)
+        if self.buckets:
+            self.bucket_cut, self.bucket_offset = self.buckets[0][0], self.buckets[0][1]     # (kept: first bucket, for introspection / tests)
 
     def refresh_dgrad_weights(self):
         """flipped/transposed bf16 weight copies for the data-gradient pass, all layers in one launch"""
@@ -431,11 +445,13 @@ class Graph(object):
         if self._repack_event is not None:        # the data-gradient weight copies were refreshed on the side stream (refresh_dgrad_async)
             torch.cuda.current_stream(self.dev).wait_event(self._repack_event)
             self._repack_event = None
+        cuts = {cut: (lo, hi) for cut, lo, hi in self.buckets} if self.on_bucket is not None else {}
         for i, f in enumerate(self.bwd):
             f()
-            if i == self.bucket_cut and self.on_bucket is not None:
+            if i in cuts:
                 self.flush_wgrad()
-                self.on_bucket()          # every gradient of the late-layer bucket has been enqueued (main + wgrad stream)
+                lo, hi = cuts[i]
+                self.on_bucket(lo, self.ps.n if hi is None else hi)   # every gradient of this bucket has been enqueued (main + wgrad stream)
         self.flush_wgrad()
         if side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(side)

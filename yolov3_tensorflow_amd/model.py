@@ -152,12 +152,11 @@ class YOLOv3Model(object):
             ga, gb = self._graphs
             dp = self.world_size > 1
             if ga is None:
-                cut = g.bucket_offset
-                overlap = dp and self.overlap_allreduce and 0 < cut < g.ps.n
-                g.on_bucket = (lambda: self._allreduce_bucket(cut, g.ps.n)) if overlap else None
+                overlap = dp and self.overlap_allreduce and bool(g.buckets)
+                g.on_bucket = self._allreduce_bucket if overlap else None       # called with (lo, hi) as each stage's gradients are complete
                 self._fwd_bwd()
                 if dp:
-                    self._allreduce_bucket(0, cut if overlap else g.ps.n)
+                    self._allreduce_bucket(0, g.bucket_tail if overlap and g.bucket_tail else g.ps.n)
             else:
                 ga.replay()
                 if dp:
