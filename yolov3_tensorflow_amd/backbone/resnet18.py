@@ -1,34 +1,29 @@
-"""ResNet-18 variant of the reference (backbone/resnet18.py:14-69): 3x3 s2 stem, BN -> max-pool -> ReLU, four modules of two
-blocks; the first block of EVERY module has a 1x1-conv + BN shortcut."""
+"""ResNet-18 variant of the reference (backbone/resnet18.py:14-69), described as data: a 3x3 stride-2 stem followed by
+BatchNorm -> max-pool -> ReLU, then four stages of two basic blocks.  Unlike torchvision's ResNet the first block of EVERY stage
+(also the stride-1 one) has a 1x1-conv + BatchNorm projection shortcut.  Layers are created in the reference's order, so the Keras
+auto-names (conv2d_k, batch_normalization_v1_k) line up with its checkpoints."""
 from yolov3_tensorflow_amd.backbone.basic_backbone import BasicBackbone
+
+STAGES = ((64, 1), (128, 2), (256, 2), (512, 2))          # (width, stride of the stage's first block): outputs at /4, /8, /16, /32
+BLOCKS_PER_STAGE = 2
 
 
 class ResNet18(BasicBackbone):
 
     @classmethod
-    def _residual_block(cls, input_x, filters, is_nin=True, **conv_params):
-        """reference :17-35"""
-        residual = cls.conv_bn(input_x, filters, **conv_params)
-        residual = cls.activation(residual)
-        conv_params.update(strides=(1, 1))
-        residual = cls.conv_bn(residual, filters, **conv_params)
-        identity = cls.element_wise_add(input_x, residual, is_nin=is_nin)
-        return cls.activation(identity)
-
-    @classmethod
-    def _residual_module(cls, input_x, filters, **conv_params):
-        """reference :37-50"""
-        first_block = cls._residual_block(input_x, filters, is_nin=True, **conv_params)
-        return cls._residual_block(first_block, filters, is_nin=False)
+    def _basic_block(cls, x, width, stride, project):
+        """conv3x3(stride)-BN-ReLU-conv3x3-BN, plus the shortcut (1x1 conv + BN when ``project``), ReLU after the sum (reference :17-35)"""
+        branch = cls.activation(cls.conv_bn(x, width, strides=(stride, stride)))
+        branch = cls.conv_bn(branch, width, strides=(1, 1))
+        return cls.activation(cls.element_wise_add(x, branch, is_nin=project))
 
     @classmethod
     def build(cls, input_x):
-        """reference :52-69 -> (stride-8, stride-16, stride-32) features"""
-        net = cls.conv_bn(input_x, filters=64, kernel_size=(3, 3), strides=(2, 2), padding='same')
-        net = cls.max_pooling(net)
-        net = cls.activation(net)
-        net = cls._residual_module(net, filters=64)
-        sub_stride_8_net = cls._residual_module(net, filters=128, strides=(2, 2))
-        sub_stride_16_net = cls._residual_module(sub_stride_8_net, filters=256, strides=(2, 2))
-        sub_stride_32_net = cls._residual_module(sub_stride_16_net, filters=512, strides=(2, 2))
-        return sub_stride_8_net, sub_stride_16_net, sub_stride_32_net
+        """-> the (stride-8, stride-16, stride-32) feature maps (reference :52-69)"""
+        x = cls.activation(cls.max_pooling(cls.conv_bn(input_x, filters=64, kernel_size=(3, 3), strides=(2, 2), padding='same')))
+        taps = []
+        for width, stride in STAGES:
+            for b in range(BLOCKS_PER_STAGE):
+                x = cls._basic_block(x, width, stride if b == 0 else 1, project=(b == 0))
+            taps.append(x)
+        return tuple(taps[1:])

@@ -1,39 +1,28 @@
-"""Pre-activation ResNet-18 of the reference (backbone/resnet18_v2.py:10-74)."""
+"""Pre-activation ResNet-18 of the reference (backbone/resnet18_v2.py:10-74), described as data: a bare 3x3 stride-2 stem (no
+BatchNorm) and max-pool, four stages of two pre-activation blocks, and a closing BatchNorm + ReLU on each of the three taps."""
 from yolov3_tensorflow_amd.backbone.basic_backbone import BasicBackbone
+from yolov3_tensorflow_amd.backbone.resnet18 import STAGES, BLOCKS_PER_STAGE
 
 
 class ResNet18_v2(BasicBackbone):
 
     @classmethod
-    def _residual_v2_block(cls, input_x, filters, is_nin=True, **conv_params):
-        """reference :13-37 -- the NIN shortcut starts from the PRE-ACTIVATED tensor (:33-34), the identity one from the input (:36)"""
-        pre_activation = cls.bn_activation(input_x)
-        residual = cls.convolution(pre_activation, filters=filters, **conv_params)
-        conv_params.update(strides=(1, 1))
-        residual = cls.bn_activation(residual)
-        residual = cls.convolution(residual, filters=filters, **conv_params)
-        if is_nin:
-            identity = cls.element_wise_add(pre_activation, residual, is_nin=True)
-        else:
-            identity = cls.element_wise_add(input_x, residual, is_nin=False)
-        return identity.g.materialize(identity, relu=False)     # the block output is a stored tensor (no activation follows)
-
-    @classmethod
-    def _residual_v2_module(cls, input_x, filters, **conv_params):
-        """reference :39-52"""
-        first_block = cls._residual_v2_block(input_x, filters, is_nin=True, **conv_params)
-        return cls._residual_v2_block(first_block, filters, is_nin=False)
+    def _preact_block(cls, x, width, stride, project):
+        """BN-ReLU-conv3x3(stride)-BN-ReLU-conv3x3 + shortcut.  The projection shortcut (1x1 conv + BN) branches off the PRE-ACTIVATED
+        tensor, the identity shortcut off the block input (reference :33-36); nothing follows the sum, so it is stored as it is."""
+        pre = cls.bn_activation(x)
+        branch = cls.convolution(pre, filters=width, strides=(stride, stride))
+        branch = cls.convolution(cls.bn_activation(branch), filters=width, strides=(1, 1))
+        total = cls.element_wise_add(pre if project else x, branch, is_nin=project)
+        return total.g.materialize(total, relu=False)
 
     @classmethod
     def build(cls, input_x):
-        """reference :54-74 (stem conv has no BN; trailing BN+ReLU on the three outputs)"""
-        net = cls.convolution(input_x, filters=64, kernel_size=(3, 3), strides=(2, 2), padding='same')
-        net = cls.max_pooling(net)
-        net = cls._residual_v2_module(net, filters=64)
-        sub_stride_8_net = cls._residual_v2_module(net, filters=128, strides=(2, 2))
-        sub_stride_16_net = cls._residual_v2_module(sub_stride_8_net, filters=256, strides=(2, 2))
-        sub_stride_32_net = cls._residual_v2_module(sub_stride_16_net, filters=512, strides=(2, 2))
-        sub_stride_8_net = cls.bn_activation(sub_stride_8_net)
-        sub_stride_16_net = cls.bn_activation(sub_stride_16_net)
-        sub_stride_32_net = cls.bn_activation(sub_stride_32_net)
-        return sub_stride_8_net, sub_stride_16_net, sub_stride_32_net
+        """-> the (stride-8, stride-16, stride-32) feature maps, each through a final BN + ReLU (reference :54-74)"""
+        x = cls.max_pooling(cls.convolution(input_x, filters=64, kernel_size=(3, 3), strides=(2, 2), padding='same'))
+        taps = []
+        for width, stride in STAGES:
+            for b in range(BLOCKS_PER_STAGE):
+                x = cls._preact_block(x, width, stride if b == 0 else 1, project=(b == 0))
+            taps.append(x)
+        return tuple(cls.bn_activation(t) for t in taps[1:])
