@@ -36,48 +36,34 @@ class YOLOv3Detector(object):
         return YOLOv3Model(self, [int(v) for v in input_image_size], [int(c) for c in head_channel_nums], list(head_names),
                            batch_size=batch_size, device=device, seed=seed)
 
-    def _detection_head(self, nets, head_channel_nums, head_names):
-        """reference :61-86 -> (head_8, head_16, head_32) raw conv outputs (float32, channel-padded)"""
-        sub_stride_8_net, sub_stride_16_net, sub_stride_32_net = nets
-        stride_8_channel_num, stride_16_channel_num, stride_32_channel_num = head_channel_nums
-        stride_8_head_name, stride_16_head_name, stride_32_head_name = head_names
-        head_32_feature = self._yolov3_stride_32_head(sub_stride_32_net, stride_32_channel_num, stride_32_head_name)
-        merge_net, head_16_feature = self._yolov3_stride_16_head(sub_stride_32_net, sub_stride_16_net,
-                                                                 stride_16_channel_num, stride_16_head_name)
-        head_8_feature = self._yolov3_stride_8_head(merge_net, sub_stride_8_net, stride_8_channel_num, stride_8_head_name)
-        return head_8_feature, head_16_feature, head_32_feature
+    # the two top-down levels of the neck (reference :103-151): kernel / width of the conv applied to the coarser feature before it is
+    # up-sampled, width of the 1x1 conv after the concatenation with the backbone tap, width of the 3x3 conv in front of the detection conv
+    TOP_DOWN = (dict(top_kernel=(3, 3), top_width=256, merge_width=256, out_width=512),      # /32 -> /16
+                dict(top_kernel=(1, 1), top_width=128, merge_width=128, out_width=256))      # /16 -> /8
+
+    def _cbr(self, x, width, kernel_size):
+        """conv -> BatchNorm -> ReLU with the backbone's factories"""
+        return self.backbone.activation(self.backbone.conv_bn(x, filters=width, kernel_size=kernel_size, strides=(1, 1)))
 
     def _detect_conv(self, net, channel_num, name):
-        """keras Conv2D(1x1, RandomNormal(0.01), bias, no regulariser) (reference :98-100,123-125,148-150)"""
+        """the detection convolution: 1x1, RandomNormal(0.01) kernel, bias, no regulariser (reference :98-100,123-125,148-150)"""
         return self.backbone.convolution(net, channel_num, kernel_size=(1, 1), use_bias=True, name=name,
                                          kernel_initializer='random_normal_0.01')
 
-    def _yolov3_stride_32_head(self, sub_stride_32_net, stride_32_channel_num, stride_32_head_name):
-        """reference :88-101"""
-        net = self.backbone.conv_bn(sub_stride_32_net, 512)
-        net = self.backbone.activation(net)
-        return self._detect_conv(net, stride_32_channel_num, stride_32_head_name)
-
-    def _yolov3_stride_16_head(self, stride_32_feature, sub_stride_16_net, stride_16_channel_num, stride_16_head_name):
-        """reference :103-126"""
-        g = stride_32_feature.g
-        net = self.backbone.conv_bn(stride_32_feature, filters=256, strides=(1, 1))
-        net = self.backbone.activation(net)
-        merge_net = g.concat(g.up_sample(net), sub_stride_16_net)
-        merge_net = self.backbone.conv_bn(merge_net, filters=256, kernel_size=(1, 1))
-        merge_net = self.backbone.activation(merge_net)
-        net = self.backbone.conv_bn(merge_net, filters=512, kernel_size=(3, 3))
-        net = self.backbone.activation(net)
-        return merge_net, self._detect_conv(net, stride_16_channel_num, stride_16_head_name)
-
-    def _yolov3_stride_8_head(self, stride_16_feature, sub_stride_8_net, stride_8_channel_num, stride_8_head_name):
-        """reference :128-151"""
-        g = stride_16_feature.g
-        net = self.backbone.conv_bn(stride_16_feature, filters=128, kernel_size=(1, 1))
-        net = self.backbone.activation(net)
-        merge_net = g.concat(g.up_sample(net), sub_stride_8_net)
-        merge_net = self.backbone.conv_bn(merge_net, filters=128, kernel_size=(1, 1))
-        merge_net = self.backbone.activation(merge_net)
-        merge_net = self.backbone.conv_bn(merge_net, filters=256, kernel_size=(3, 3))
-        merge_net = self.backbone.activation(merge_net)
-        return self._detect_conv(merge_net, stride_8_channel_num, stride_8_head_name)
+    def _detection_head(self, nets, head_channel_nums, head_names):
+        """FPN-style neck + the three detection convolutions (reference :61-151) -> (head_8, head_16, head_32) raw outputs (float32,
+        channel-padded).  Layers are created coarse to fine, as in the reference: /32 head, then the /16 level, then the /8 level; the
+        feature handed down from the /16 level is its merged 1x1 output, the /8 level detects on its 3x3 output."""
+        tap_8, tap_16, tap_32 = nets
+        outputs = [self._detect_conv(self._cbr(tap_32, 512, (3, 3)), head_channel_nums[2], head_names[2])]
+        coarse = tap_32
+        for level, tap, channels, name in zip(self.TOP_DOWN, (tap_16, tap_8), (head_channel_nums[1], head_channel_nums[0]),
+                                              (head_names[1], head_names[0])):
+            g = coarse.g
+            top = self._cbr(coarse, level['top_width'], level['top_kernel'])
+            merged = self._cbr(g.concat(g.up_sample(top), tap), level['merge_width'], (1, 1))
+            feature = self._cbr(merged, level['out_width'], (3, 3))
+            outputs.append(self._detect_conv(feature, channels, name))
+            coarse = merged
+        head_32, head_16, head_8 = outputs
+        return head_8, head_16, head_32
