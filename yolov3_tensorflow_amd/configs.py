@@ -1,12 +1,14 @@
 """Module-global FLAGS with the reference's keys, defaults and derived fields (configs.py:11-106) and ``lr_func`` (:23-27).
-``FLAGS`` is an attribute-style dict (the reference uses easydict.EasyDict); call ``refresh_derived()`` after editing keys
-that other fields are derived from (the reference computes them once at import time)."""
+``FLAGS`` is an attribute-style dict (the reference uses easydict.EasyDict) filled from the DEFAULTS table below; call
+``refresh_derived()`` after editing keys that other fields are derived from (the reference computes them once at import time)."""
 import datetime
 import numpy as np
 from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
 
 
 class AttrDict(dict):
+    """dict with attribute access (FLAGS.key)"""
+
     def __getattr__(self, k):
         try:
             return self[k]
@@ -17,68 +19,72 @@ class AttrDict(dict):
         self[k] = v
 
 
-FLAGS = AttrDict()
+_MILLI = 1e-3
+SCHEDULES = {   # epoch boundaries -> learning rate (reference :14-17): a short sweep for checking, and the training schedule
+    'check': (np.array([2, 4, 6, 8, 10, 12, 14], np.int64), np.array([0.00001, 0.0001, 0.001, 0.01, 0.1, 1., 10.0], dtype=np.float64) * _MILLI),
+    'train': (np.array([20, 60, 80, 220, 260, 280, 300], np.int64), np.array([0.01, 1., 0.1, 1., 0.1, 0.01, 0.001], dtype=np.float64) * _MILLI),
+}
 
-FLAGS.check_step_epoch = np.array([2, 4, 6, 8, 10, 12, 14], np.int64)                                   # reference :14
-FLAGS.check_step_lr = np.array([0.00001, 0.0001, 0.001, 0.01, 0.1, 1., 10.0], dtype=np.float64) * 1e-3  # :15
-FLAGS.train_step_epoch = np.array([20, 60, 80, 220, 260, 280, 300], np.int64)                           # :16
-FLAGS.train_step_lr = np.array([0.01, 1., 0.1, 1., 0.1, 0.01, 0.001], dtype=np.float64) * 1e-3          # :17
-FLAGS.step_epoch = FLAGS.train_step_epoch
-FLAGS.step_lr = FLAGS.train_step_lr
-
-
-def lr_func(epoch):
-    """reference :23-27"""
-    i = 0
-    while i < len(FLAGS.step_epoch) and epoch > FLAGS.step_epoch[i]:
-        i += 1
-    return FLAGS.step_lr[i]
-
-
-FLAGS.train_set_dir = 'dataset/test_sample/images'
-FLAGS.train_label_path = 'dataset/test_sample/label.txt'
-FLAGS.test_set_dir = 'dataset/test_sample/images'
-FLAGS.test_label_path = 'dataset/test_sample/label.txt'
-FLAGS.input_image_size = np.array([384, 480, 3], dtype=np.int64)  # [H, W, C]
-FLAGS.anchor_boxes = [[(0.06618181818181816, 0.1025177510694752), (0.18544278606965178, 0.13160367921287464),
+DEFAULTS = dict(
+    train_set_dir='dataset/test_sample/images',
+    train_label_path='dataset/test_sample/label.txt',
+    test_set_dir='dataset/test_sample/images',
+    test_label_path='dataset/test_sample/label.txt',
+    input_image_size=np.array([384, 480, 3], dtype=np.int64),
+    anchor_boxes=[[(0.06618181818181816, 0.1025177510694752), (0.18544278606965178, 0.13160367921287464),
                       (0.13, 0.32733333333333337)],
                       [(0.13, 0.32733333333333337), (0.303806787732042, 0.34370030784316496)],
                       [(0.303806787732042, 0.34370030784316496), (0.4667050847457627, 0.5281262429095761),
-                      (0.7906945888923907, 0.7888860433597275)]]  # [W, H] of head_8, head_16, head_32 (reference :37-41)
-FLAGS.class_num = 0
-FLAGS.head_names = ['yolov3_head_8', 'yolov3_head_16', 'yolov3_head_32', ]
-FLAGS.iou_thresh = 0.8
-FLAGS.loss_weights = [(5, 5, 0.05, 3, 1), (8, 8, 0.05, 2, 1), (10, 10, 0.05, 2, 1)]
-FLAGS.train_set_size = 20
-FLAGS.val_set_size = 20
-FLAGS.batch_size = 3
-FLAGS.rectified_coord_num = 1464
-FLAGS.rectified_loss_weight = [1.0, 1.0, 1.0]
-FLAGS.epoch = 300
-FLAGS.init_lr = 0.0002
-FLAGS.mode = 'train'  # train, test, predict, save_pb, save_serving
-FLAGS.model_backbone = YOLOv3Detector.BACKBONE_RESNET_18
-FLAGS.optimizer = 'radam'  # sgdm, adam, radam
-FLAGS.is_augment = True
-FLAGS.is_label_smoothing = False
-FLAGS.is_focal_loss = False
-FLAGS.focal_alpha = 1.0
-FLAGS.focal_gamma = 2.0
-FLAGS.is_gradient_harmonized = False
-FLAGS.is_tiou_recall = False
-FLAGS.ckpt_period = 50
-FLAGS.stop_patience = 500
-FLAGS.stop_min_delta = 0.0001
+                      (0.7906945888923907, 0.7888860433597275)]],
+    class_num=0,
+    head_names=['yolov3_head_8', 'yolov3_head_16', 'yolov3_head_32', ],
+    iou_thresh=0.8,
+    loss_weights=[(5, 5, 0.05, 3, 1), (8, 8, 0.05, 2, 1), (10, 10, 0.05, 2, 1)],
+    train_set_size=20,
+    val_set_size=20,
+    batch_size=3,
+    rectified_coord_num=1464,
+    rectified_loss_weight=[1.0, 1.0, 1.0],
+    epoch=300,
+    init_lr=0.0002,
+    mode='train',
+    model_backbone=YOLOv3Detector.BACKBONE_RESNET_18,
+    optimizer='radam',
+    is_augment=True,
+    is_label_smoothing=False,
+    is_focal_loss=False,
+    focal_alpha=1.0,
+    focal_gamma=2.0,
+    is_gradient_harmonized=False,
+    is_tiou_recall=False,
+    ckpt_period=50,
+    stop_patience=500,
+    stop_min_delta=0.0001,
+    root_path='',
+    confidence_thresh=0.8,
+    nms_thresh=0.4,
+    save_path='dataset/test_result/',
+    image_root_path=None,
+    gpu_mode='gpu',
+    gpu_num=1,
+    visible_gpu='0',
+    full_state_resume=False,
+)
+
+FLAGS = AttrDict()
+for _name, (_epochs, _rates) in SCHEDULES.items():
+    FLAGS[_name + '_step_epoch'], FLAGS[_name + '_step_lr'] = _epochs, _rates
+FLAGS.step_epoch, FLAGS.step_lr = FLAGS.train_step_epoch, FLAGS.train_step_lr
+
+
+def lr_func(epoch):
+    """piecewise-constant schedule: the rate of the first boundary that ``epoch`` does not exceed (reference :23-27)"""
+    passed = int(np.searchsorted(np.asarray(FLAGS.step_epoch), epoch, side='left'))     # number of boundaries with boundary < epoch
+    return FLAGS.step_lr[passed]
+
+
+FLAGS.update(DEFAULTS)
 FLAGS.lr_func = lr_func
-FLAGS.root_path = ''
-FLAGS.confidence_thresh = 0.8
-FLAGS.nms_thresh = 0.4
-FLAGS.save_path = 'dataset/test_result/'
-FLAGS.image_root_path = None
-FLAGS.gpu_mode = 'gpu'
-FLAGS.gpu_num = 1
-FLAGS.visible_gpu = '0'
-FLAGS.full_state_resume = False   # not in the reference: also checkpoint / restore the RAdam moments, step counter, rectified-image counter, epoch
 
 
 def refresh_derived():

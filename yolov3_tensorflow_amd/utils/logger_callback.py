@@ -44,37 +44,30 @@ class DetailLossLogger(object):
         if self.verbose in (1, 2):
             self.log(logs or {})
 
+    HEADS = ('/8:', '/16:', '/32:')
+    SUB_LOSSES = (('rectified_loss', 'rectified_coord_loss'), ('xy_loss', 'coord_loss_xy'), ('wh_loss', 'coord_loss_wh'),
+                  ('noobj_iou_loss', 'noobj_iou_loss'), ('obj_iou_loss', 'obj_iou_loss'), ('cls_loss', 'class_loss'))
+
+    @staticmethod
+    def _field(key, value):
+        """' - key: value' with the reference's number format: 4 decimals above 1e-3, scientific below (reference :132-138)"""
+        if isinstance(value, str):
+            return ' - %s: %s' % (key, value)
+        return (' - %s: %.4f' if value > 1e-3 else ' - %s: %.4e') % (key, value)
+
     def format(self, logs):
-        """reference :87-139 -> the message string"""
-        info = '\n - %.0fs' % (time.time() - self._last_update)
-        log_values = [('lr', logs['lr'])]
-        for k in self.metrics:
-            if k in logs:
-                log_values.append((k, logs[k]))
+        """the reference's message (:87-139): a summary row (seconds, lr, metrics, the two regulariser sums with their term counts), then
+        per head a title row and a row of the six sub-losses; every row ends with the reference's ' -  : ' separator + newline"""
         gamma_sum, gamma_n, kernel_sum, kernel_n = self.model.regularization_losses()
-        log_values.append(('gamma_regular_loss({})'.format(gamma_n), gamma_sum))
-        log_values.append(('kernel_regular_loss({})'.format(kernel_n), kernel_sum))
-        log_values.append((' ', '\n'))
-        lo = self.loss_object
-        rect, xy, wh, noobj, obj, cls = (lo.rectified_coord_loss, lo.coord_loss_xy, lo.coord_loss_wh, lo.noobj_iou_loss, lo.obj_iou_loss,
-                                         lo.class_loss)
-        for i, head in enumerate(('/8:\n', '/16:\n', '/32:\n')):
-            log_values.append(('head', head))
-            log_values.append(('rectified_loss', rect[i]))
-            log_values.append(('xy_loss', xy[i]))
-            log_values.append(('wh_loss', wh[i]))
-            log_values.append(('noobj_iou_loss', noobj[i]))
-            log_values.append(('obj_iou_loss', obj[i]))
-            log_values.append(('cls_loss', cls[i]))
-            log_values.append((' ', '\n'))
-        for key, value in log_values:
-            if isinstance(value, str):
-                info += ' - %s: %s' % (key, value)
-            elif value > 1e-3:
-                info += ' - %s: %.4f' % (key, value)
-            else:
-                info += ' - %s: %.4e' % (key, value)
-        return info
+        summary = [('lr', logs['lr'])] + [(k, logs[k]) for k in self.metrics if k in logs]
+        summary += [('gamma_regular_loss(%d)' % gamma_n, gamma_sum), ('kernel_regular_loss(%d)' % kernel_n, kernel_sum)]
+        end_of_row = self._field(' ', '\n')
+        text = '\n - %.0fs' % (time.time() - self._last_update) + ''.join(self._field(k, v) for k, v in summary) + end_of_row
+        per_head = [getattr(self.loss_object, attr) for _, attr in self.SUB_LOSSES]
+        for i, head in enumerate(self.HEADS):
+            text += self._field('head', head + '\n')
+            text += ''.join(self._field(label, values[i]) for (label, _), values in zip(self.SUB_LOSSES, per_head)) + end_of_row
+        return text
 
     def log(self, logs=None):
         logging.info(self.format(logs or {}))
