@@ -622,6 +622,9 @@ LOSS_CASES = [
     dict(name='c80_norect_empty', grid=[(16, 16), (8, 8), (4, 4)], C=80, N=4, T=6, rect=-1, focal=False, tiou=False, empty=2),
     dict(name='c0_rect', grid=[(12, 16), (6, 8), (3, 4)], C=0, N=2, T=5, rect=0, focal=False, tiou=False, empty=None),
     dict(name='c20_focal_tiou', grid=[(16, 16), (8, 8), (4, 4)], C=20, N=3, T=7, rect=-1, focal=True, tiou=True, empty=None),
+    # duplicates in one cell + anchor, a centre exactly on the right / bottom border (floor index = W / H: clamped), a
+    # centre exactly on a cell boundary, a box as large as the image and a tiny one
+    dict(name='c5_edges', grid=[(16, 16), (8, 8), (4, 4)], C=5, N=4, T=6, rect=-1, focal=False, tiou=False, empty=None, edges=True),
 ]
 
 
@@ -638,6 +641,12 @@ def test_loss_fwd_bwd_vs_oracle(dev, case):
     ldc = [ops.pad_channels(b * L) for b in B]
     raw = [torch.randn(N, h, w, b, L, generator=gen) * 0.8 for (h, w), b in zip(grid, B)]
     lab = make_labels(gen, N, T, Cn, case['empty'])
+    if case.get('edges'):
+        lab[0, :3] = torch.tensor([[0.40, 0.55, 0.30, 0.20, 2.0], [0.40, 0.55, 0.30, 0.20, 2.0], [0.41, 0.56, 0.30, 0.20, 3.0]])
+        lab[1, :2] = torch.tensor([[1.0, 1.0, 0.20, 0.30, 1.0], [0.5, 0.25, 0.10, 0.10, 0.0]])      # border; exact cell boundary at every head
+        lab[1, 2:] = -1.0
+        lab[2, :2] = torch.tensor([[0.5, 0.5, 1.0, 1.0, 4.0], [0.3, 0.3, 0.004, 0.004, 0.0]])
+        lab[2, 2:] = -1.0
     orc = YOLOv3LossOracle(grid, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=case['rect'], rectified_loss_weight=[1.0, 0.5, 2.0],
                            is_focal_loss=case['focal'], focal_alpha=1.0, focal_gamma=2.0, is_tiou_recall=case['tiou'])
     rr = [r.clone().requires_grad_(True) for r in raw]
@@ -666,8 +675,13 @@ def test_loss_fwd_bwd_vs_oracle(dev, case):
     ops.loss_fwd_bwd(cfg, N, N, logits, lab.to(dev), cur, terms, total, ws, dlogits=dl, dlogits_bf16=dlb, assign_out=assign,
                      resp_iou_out=riou)
     torch.cuda.synchronize()
-    torch.testing.assert_close(terms.cpu(), terms_ref, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(total.cpu()[0], total_ref.detach(), rtol=1e-4, atol=1e-5)
+    # a centre exactly on the border makes the reference's own arithmetic produce NaN in that head's xy term (0 * log 0): the kernel must
+    # reproduce it in the same place, not hide it
+    nan_ok = bool(case.get('edges'))
+    if nan_ok:
+        assert torch.isnan(terms_ref).sum() == 1 and torch.equal(torch.isnan(terms.cpu()), torch.isnan(terms_ref))
+    torch.testing.assert_close(terms.cpu(), terms_ref, rtol=1e-4, atol=1e-5, equal_nan=nan_ok)
+    torch.testing.assert_close(total.cpu()[0], total_ref.detach(), rtol=1e-4, atol=1e-5, equal_nan=nan_ok)
     # rectified counter semantics (yolov3_loss.py:125-130,152)
     expect_cur = N if (case['rect'] >= 0) else 0
     assert int(cur.cpu()[0]) == expect_cur
@@ -691,12 +705,15 @@ def test_loss_fwd_bwd_vs_oracle(dev, case):
         got = dl[h].cpu()
         assert torch.count_nonzero(got[..., B[h] * L:]) == 0
         denom = gref.abs().max().item()
-        torch.testing.assert_close(got[..., :B[h] * L], gref, rtol=1e-3, atol=1e-5 * max(denom, 1.0))
-        torch.testing.assert_close(dlb[h].float().cpu(), got.to(ACT()).float(), rtol=0, atol=0)
+        if nan_ok:
+            assert torch.equal(torch.isnan(got[..., :B[h] * L]), torch.isnan(gref))
+            denom = torch.nan_to_num(gref).abs().max().item()
+        torch.testing.assert_close(got[..., :B[h] * L], gref, rtol=1e-3, atol=1e-5 * max(denom, 1.0), equal_nan=nan_ok)
+        torch.testing.assert_close(dlb[h].float().cpu(), got.to(ACT()).float(), rtol=0, atol=0, equal_nan=nan_ok)
     # second call: counter advanced -> rectified term switches off when current_num > rectified_coord_num
     ops.loss_fwd_bwd(cfg, N, N, logits, lab.to(dev), cur, terms, total, ws, dlogits=dl)
     total2 = orc.loss_heads(lab.reshape(N, -1), [r.clone() for r in raw])
-    torch.testing.assert_close(total.cpu()[0], total2.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(total.cpu()[0], total2.detach(), rtol=1e-4, atol=1e-5, equal_nan=nan_ok)
 
 
 # ------------------------------------------------------------------------------------------------------------------ RAdam
