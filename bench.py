@@ -86,8 +86,9 @@ def conv_kernel_roofline(model, steps):
 
     ops_fwd, ops_dg = ops.conv2d_fwd, ops.conv2d_dgrad
     ops.conv2d_fwd, ops.conv2d_dgrad = timed(ops_fwd), timed(ops_dg)
-    saved = model.overlap_wgrad
+    saved, saved_bucket = model.overlap_wgrad, model.g.on_bucket
     model.overlap_wgrad = False        # time each launch alone on the stream (no weight-gradient GEMM sharing the CUs)
+    model.g.on_bucket = None           # purely local passes: no gradient all-reduce is issued (data-parallel runs call this on every rank)
     try:
         for _ in range(steps):
             model._fwd_bwd()
@@ -95,7 +96,7 @@ def conv_kernel_roofline(model, steps):
         torch.cuda.synchronize()
     finally:
         ops.conv2d_fwd, ops.conv2d_dgrad = ops_fwd, ops_dg
-        model.overlap_wgrad = saved
+        model.overlap_wgrad, model.g.on_bucket = saved, saved_bucket
     out = {}
     for name, sel in (('strip', True), ('other', False)):
         rs = [r for r in records if r[3] == sel]
@@ -171,11 +172,13 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
     from yolov3_tensorflow_amd import backend
     backend.set_compute_dtype(args.dtype)
+    if os.environ.get('YOLO_BENCH_SHARE_GPU'):          # rehearsal aid: several ranks on one GPU (with YOLO_DIST_BACKEND=gloo)
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda:%d' % local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl')
+        dist.init_process_group(os.environ.get('YOLO_DIST_BACKEND', 'nccl'))      # 'nccl' = RCCL; gloo only for single-GPU rehearsals
 
     H = W = args.size
     from yolov3_tensorflow_amd import ops
@@ -238,8 +241,10 @@ def main():
     if rank == 0 and gflop is not None:
         out['step_tflops'] = round(ips / world * gflop / 1000.0, 2)      # per GPU, whole step, algorithmic conv FLOPs
         out['step_mfma_frac'] = round(out['step_tflops'] / PEAK_BF16_TFLOPS, 4)
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank runs the (collective-free) measurement passes so that the ranks stay in step; rank 0 reports its own numbers
         rf = conv_kernel_roofline(model, max(2, min(5, args.steps)))
+    if rank == 0 and not args.no_roofline:
         tf, avg_ms, per_step = rf['strip']
         traffic, traffic_src = strip_hbm_traffic()
         out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel (3x3 stride-1 conv forward + data-gradient launches, all tile variants)',

@@ -12,7 +12,7 @@ def setup_data_parallel(model, backend=None):
         return False
     import torch.distributed as dist
     if not dist.is_initialized():
-        dist.init_process_group(backend or 'nccl')
+        dist.init_process_group(backend or os.environ.get('YOLO_DIST_BACKEND', 'nccl'))
     model.set_distributed(dist.get_world_size(), dist.get_rank())
     broadcast_weights(model)
     return True
