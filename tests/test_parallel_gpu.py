@@ -91,3 +91,22 @@ def test_two_ranks_on_one_gpu(tmp_path):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, 'rank %d failed:\n%s' % (r, out[-3000:])
         assert 'RESULT rank %d' % r in out
+
+
+def test_bench_command_at_two_ranks():
+    """the driver's multi-GPU command line, rehearsed with both ranks on this one GPU (gloo): bench.py must reach its JSON line --
+    in particular nothing after the timed loop may issue a collective on a subset of the ranks"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import json
+    env = dict(os.environ, YOLO_BENCH_SHARE_GPU='1', YOLO_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29623', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--size', '224',
+           '--batch', '4', '--classes', '13']
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+    assert p.returncode == 0, p.stdout[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-3000:]                       # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 8 and out['config']['parallelism'] == 'dp2' and out['value'] > 0
+    assert 'roofline' in out and 'cpu_baseline' not in out          # the CPU baseline is an N = 1 item
