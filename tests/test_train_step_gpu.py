@@ -238,7 +238,7 @@ def test_loss_curve_graph_replay():
 
 
 def test_eager_two_stream_and_bucketed_allreduce_match_serial():
-    """the default execution mode (eager, weight-gradient GEMMs on a second stream, late-layer gradient bucket all-reduced on a
+    """the default execution mode (eager, weight-gradient GEMMs on a second stream, gradient buckets (by backbone stage) all-reduced on a
     communication stream during the rest of the backward pass; here a 1-rank RCCL group, i.e. the identity) must give the same weights
     as single-stream serial execution, up to the float atomics' summation order in the weight gradients."""
     if not torch.cuda.is_available():

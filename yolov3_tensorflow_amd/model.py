@@ -46,7 +46,7 @@ class YOLOv3Model(object):
         # eager + overlap; the host stays ahead of the GPU (~270 launches per step).
         self.use_hip_graph = False
         self.overlap_wgrad = True          # weight-gradient GEMMs on a second stream (see engine.Graph.run_backward)
-        self.overlap_allreduce = True      # data parallel: late-layer gradient bucket all-reduced while the early layers still run backward
+        self.overlap_allreduce = True      # data parallel: each stage's gradient bucket is all-reduced while the earlier layers still run backward
         self._comm_stream = None
         self._pending = []
         self.loss_value = torch.zeros(1, device=self.device)
