@@ -51,7 +51,8 @@ def test_config1_train_steps_and_box_indices():
         ref.append(o.step(x, y)[0])
     print('config1 loss gpu', gpu, 'oracle', ref)
     for a, b in zip(gpu, ref):
-        assert abs(a - b) <= 3e-3 * abs(b), (gpu, ref)     # bf16 path vs float32 oracle (see DESIGN.md "precision")
+        assert abs(a - b) <= 1e-3 * abs(b), (gpu, ref)     # north_star's 1e-3: bf16 path vs float32 oracle (measured 2.4e-4 .. 8.5e-4; the
+                                                            # kernels are deterministic, so this does not flake -- see DESIGN.md "precision")
 
     # ---- decoded box indices: predict (inference-mode BN) -> merged layout -> GPU decode -> score filter ----
     x = images[6:8]
