@@ -108,3 +108,30 @@ def test_label_decoder_matches_oracle():
     for (a, b), (c, d) in zip(got, ref):
         np.testing.assert_array_equal(a, c.numpy())
         np.testing.assert_array_equal(b, d.numpy())
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_product_nms_matches_oracle_on_adversarial_rows(seed):
+    """the product's vectorised host NMS against the pinned oracle on rows with tied scores, duplicate boxes, degenerate (zero-area) boxes,
+    empty heads and few classes -- the cases where sort stability, the `w <= 0` short-cut and the per-head id quirk decide the outcome"""
+    from oracle import postprocess as pp
+    from yolov3_tensorflow_amd.yolov3.yolov3_post_process import YOLOv3PostProcessor as P
+    rng = np.random.default_rng(seed)
+    heads = []
+    for k in (int(rng.integers(0, 40)), 0 if seed % 2 else int(rng.integers(1, 25)), int(rng.integers(0, 30))):
+        c = rng.uniform(0.2, 0.8, size=(k, 2))
+        half = rng.uniform(0.0, 0.25, size=(k, 2)) * (rng.uniform(size=(k, 1)) > 0.1)         # some zero-area boxes
+        rows = np.concatenate([c - half, c + half, rng.uniform(0.5, 1, (k, 1)), rng.uniform(0.5, 1, (k, 1)),
+                               rng.integers(0, 3, (k, 1)).astype(np.float64), np.round(rng.uniform(0.3, 1, (k, 1)), 1)], axis=1)   # tied scores
+        if k > 4:
+            rows[1] = rows[0]                                                                  # exact duplicates
+            rows[3, :4] = rows[2, :4]
+        heads.append(rows)
+    for quirk in (True, False):
+        want = pp.apply_nms([h.copy() for h in heads], 0.35, reference_quirk=quirk)
+        got = P.apply_nms([h.copy() for h in heads], 0.35, fixed_indices=not quirk)
+        for w, g in zip(want, got):
+            np.testing.assert_array_equal(np.asarray(g, dtype=np.float64).reshape(-1, 9), np.asarray(w, dtype=np.float64).reshape(-1, 9))
+    size = np.array([480, 384, 480, 384])
+    for w, g in zip(pp.resize_boxes(want, size), P.resize_boxes(got, size)):
+        np.testing.assert_array_equal(np.asarray(g, dtype=np.float64).reshape(-1, 9), np.asarray(w, dtype=np.float64).reshape(-1, 9))

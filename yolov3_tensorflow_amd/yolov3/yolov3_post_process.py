@@ -1,7 +1,8 @@
 """YOLOv3PostProcessor with the reference's static methods (yolov3/yolov3_post_process.py:10-205): score filter, cross-head per-class NMS,
-box rescale, drawing.  Host-side NumPy like the reference (it runs after the network on a handful of boxes); the per-prediction score /
-class arg-max can be taken from the GPU decode (YOLOv3Decoder.decode(with_scores=True)).  ``apply_nms`` reproduces the reference's
-never-advanced ``start_index`` (:81-89) by default; ``fixed_indices=True`` gives globally unique ids."""
+box rescale, drawing.  run.py uses the GPU path (filter_boxes_device / apply_nms_device); the host methods are an independent vectorised
+NumPy implementation of the same contract (array gathers, a stable arg-sort and alive-flag suppression instead of the reference's Python
+list surgery), checked bit for bit against golden vectors produced by the reference's own module (tests/golden/postprocess_*.npz).
+``apply_nms`` reproduces the reference's never-advanced ``start_index`` (:81-89) by default; ``fixed_indices=True`` gives globally unique ids."""
 import numpy as np
 
 
@@ -18,92 +19,91 @@ class YOLOv3PostProcessor(object):
 
     @staticmethod
     def filter_boxes(head_8_prediction, head_8_boxes, head_16_prediction, head_16_boxes, head_32_prediction, head_32_boxes, score_thresh):
-        """reference :20-43"""
-        f = YOLOv3PostProcessor._filter_single_head_boxes
-        return [f(head_8_prediction, head_8_boxes, score_thresh), f(head_16_prediction, head_16_boxes, score_thresh),
-                f(head_32_prediction, head_32_boxes, score_thresh)]
+        """score filter of the three decoded heads (semantics of reference :20-43) -> [rows (k, 8)] x 3"""
+        heads = ((head_8_prediction, head_8_boxes), (head_16_prediction, head_16_boxes), (head_32_prediction, head_32_boxes))
+        return [YOLOv3PostProcessor._filter_single_head_boxes(p, b, score_thresh) for p, b in heads]
+
+    @staticmethod
+    def _scores(prediction):
+        """per prediction (flattened row-major over (row, col, anchor)): score = conf * best class prob, best prob, best class (reference :49-59).
+        Without class channels the probability is 1 and the class 0, in the prediction's dtype."""
+        flat = np.asarray(prediction).reshape(-1, prediction.shape[-1])
+        conf = flat[:, 4]
+        if flat.shape[1] == 5:
+            return conf, np.ones_like(conf), np.zeros_like(conf)
+        classes = flat[:, 5:]
+        best = classes.argmax(axis=1)
+        prob = classes[np.arange(flat.shape[0]), best]
+        return prob * conf, prob, best
 
     @staticmethod
     def filter_indices(prediction, score_thresh):
         """the 'decoded box indices' of the parity criterion: flat ((row*W)+col)*B+anchor of every score > thresh (reference :57-62)"""
-        score = prediction[..., 4]
-        if prediction.shape[-1] > 5:
-            score = np.max(prediction[..., 5:], axis=-1) * score
-        return np.where(np.reshape(score > score_thresh, [-1]))[0]
+        return np.flatnonzero(YOLOv3PostProcessor._scores(prediction)[0] > score_thresh)
 
     @staticmethod
     def _filter_single_head_boxes(prediction, predict_boxes, score_thresh):
-        """reference :45-77 -> (k, 8) [x0, y0, x1, y1, conf, class prob, class index, score] in normalised units"""
-        height, width, box_num, box_len = prediction.shape
-        all_score = prediction[:, :, :, 4]
-        all_class_prob = np.ones_like(all_score)
-        all_class_indices = np.zeros_like(all_score)
-        if box_len > 5:
-            all_class_prob = np.max(prediction[:, :, :, 5:], axis=-1)
-            all_class_indices = np.argmax(prediction[:, :, :, 5:], axis=-1)
-            all_score = all_class_prob * all_score
-        pos = np.where(np.reshape(all_score > score_thresh, [-1]))
-        if len(pos[0]) == 0:
-            return np.empty(shape=(0, 8), dtype=np.float64)
-        cols = [np.take(predict_boxes[:, :, :, 0], pos) / width, np.take(predict_boxes[:, :, :, 1], pos) / height,
-                np.take(predict_boxes[:, :, :, 2], pos) / width, np.take(predict_boxes[:, :, :, 3], pos) / height,
-                np.take(prediction[:, :, :, 4], pos), np.take(all_class_prob, pos), np.take(all_class_indices, pos), np.take(all_score, pos)]
-        return np.transpose(np.concatenate(cols, axis=0))
+        """-> (k, 8) rows [x0/W, y0/H, x1/W, y1/H, conf, class prob, class index, score] of the predictions whose score exceeds the
+        threshold, in flat (row, col, anchor) order.  One fancy-index gather per table instead of the reference's eight np.take columns
+        (reference :45-77); dtype as there: float64 once an integer class index is among the columns, else the prediction's own."""
+        height, width = prediction.shape[0], prediction.shape[1]
+        score, prob, best = YOLOv3PostProcessor._scores(prediction)
+        hits = np.flatnonzero(score > score_thresh)
+        if hits.size == 0:
+            return np.empty((0, 8), dtype=np.float64)
+        corners = np.asarray(predict_boxes).reshape(-1, 4)[hits]
+        out = np.empty((hits.size, 8), dtype=np.result_type(corners.dtype, score.dtype, best.dtype))
+        out[:, 0:4] = corners / np.array([width, height, width, height], dtype=corners.dtype)
+        out[:, 4] = np.asarray(prediction).reshape(-1, prediction.shape[-1])[hits, 4]
+        out[:, 5], out[:, 6], out[:, 7] = prob[hits], best[hits], score[hits]
+        return out
 
     @staticmethod
     def apply_nms(boxes, nms_thresh, fixed_indices=False):
-        """reference :79-106"""
-        boxes = list(boxes)
-        start_index = 0
-        for i, head_boxes in enumerate(boxes):
-            end_index = len(head_boxes)
-            if end_index == 0:
-                boxes[i] = np.reshape(head_boxes, (0, 9))
+        """class-wise greedy NMS over the boxes of all three heads together (semantics of reference :79-131) -> per head the surviving rows
+        with a 9th column, the box id.  The reference numbers the boxes of EVERY head from 0 (its running start index is never advanced,
+        :81-89) and keeps a row when its id is among the survivors' ids -- of any head; that is reproduced unless ``fixed_indices``."""
+        heads = [np.asarray(b, dtype=np.float64).reshape(-1, 8) for b in boxes]
+        sizes = [len(b) for b in heads]
+        first = np.concatenate([[0], np.cumsum(sizes)[:-1]]) if fixed_indices else np.zeros(len(heads), dtype=np.int64)
+        ids = [np.arange(f, f + k, dtype=np.float64) for f, k in zip(first, sizes)]
+        if sum(sizes) == 0:
+            return [np.empty((0, 9), dtype=np.float64) for _ in heads]
+        rows = np.concatenate(heads, axis=0)
+        survivors = YOLOv3PostProcessor._greedy_nms(rows, nms_thresh)
+        kept_ids = np.unique(np.concatenate(ids)[survivors])
+        out = []
+        for b, i in zip(heads, ids):
+            if len(b) == 0:
+                out.append(np.empty((0, 9), dtype=np.float64))
                 continue
-            indices = np.expand_dims(np.arange(start_index, start_index + end_index, dtype=np.float64), axis=-1)
-            boxes[i] = np.concatenate([head_boxes, indices], axis=-1)
-            if fixed_indices:
-                start_index += end_index
-        sorted_boxes = YOLOv3PostProcessor._apply_nms(np.concatenate(boxes, axis=0), nms_thresh)
-        keep = set(box[-1] for box in sorted_boxes)
-        for i, head_boxes in enumerate(boxes):
-            if len(head_boxes) == 0:
+            tagged = np.concatenate([b, i[:, None]], axis=1)
+            out.append(list(tagged[np.isin(i, kept_ids)]))
+        return out
+
+    @staticmethod
+    def _greedy_nms(rows, nms_thresh):
+        """indices (into ``rows``) of the boxes that survive: visit in descending score (ties in input order, i.e. a stable sort), each
+        surviving box suppresses the later boxes of its own class whose IoU with it exceeds the threshold.  float64 IoU, evaluated
+        in the reference's operation order (:134-162) so that the comparison with the threshold is bit-identical."""
+        order = np.argsort(-rows[:, 7], kind='stable')
+        r = rows[order]
+        x0, y0, x1, y1, cls = r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 6]
+        area = (x1 - x0) * (y1 - y0)
+        alive = np.ones(len(r), dtype=bool)
+        for i in range(len(r) - 1):
+            if not alive[i]:
                 continue
-            boxes[i] = [box for box in head_boxes if box[-1] in keep]
-        return boxes
-
-    @staticmethod
-    def _apply_nms(boxes, nms_thresh):
-        """reference :109-131 -- greedy NMS among boxes of the same class, by descending score"""
-        sorted_boxes = sorted(boxes, key=lambda d: d[7], reverse=True)
-        index, box_num = 0, len(sorted_boxes) - 1
-        while index < box_num:
-            same = [(index + 1 + i, box) for (i, box) in enumerate(sorted_boxes[(index + 1):]) if box[6] == sorted_boxes[index][6]]
-            ious = [(i, YOLOv3PostProcessor._cal_iou(sorted_boxes[index], box)) for (i, box) in same]
-            removed = 0
-            for i, iou in ious:
-                if iou > nms_thresh:
-                    del sorted_boxes[i - removed]
-                    removed += 1
-                    box_num -= 1
-            index += 1
-        return sorted_boxes
-
-    @staticmethod
-    def _cal_iou(box, truth):
-        """reference :134-147"""
-        w = YOLOv3PostProcessor._overlap(box[0], box[2], truth[0], truth[2])
-        h = YOLOv3PostProcessor._overlap(box[1], box[3], truth[1], truth[3])
-        if w <= 0 or h <= 0:
-            return 0
-        inter_area = w * h
-        union_area = (box[2] - box[0]) * (box[3] - box[1]) + (truth[2] - truth[0]) * (truth[3] - truth[1]) - inter_area
-        return inter_area / union_area
-
-    @staticmethod
-    def _overlap(x1, x2, x3, x4):
-        """reference :150-162"""
-        return min(x2, x4) - max(x1, x3)
+            cand = np.flatnonzero(alive[i + 1:] & (cls[i + 1:] == cls[i])) + i + 1
+            if cand.size == 0:
+                continue
+            w = np.minimum(x1[i], x1[cand]) - np.maximum(x0[i], x0[cand])
+            h = np.minimum(y1[i], y1[cand]) - np.maximum(y0[i], y0[cand])
+            inter = w * h
+            with np.errstate(divide='ignore', invalid='ignore'):
+                iou = np.where((w <= 0) | (h <= 0), 0.0, inter / (area[i] + area[cand] - inter))
+            alive[cand[iou > nms_thresh]] = False
+        return order[alive]
 
     # ------------------------------------------------------------------------------------------------ GPU path (whole batch)
     @staticmethod
@@ -163,9 +163,18 @@ class YOLOv3PostProcessor(object):
 
     @staticmethod
     def resize_boxes(boxes, target_size):
-        """reference :164-176"""
-        return [head_boxes if len(head_boxes) == 0 else
-                [np.concatenate([box[:4] * target_size, box[4:]], axis=-1) for box in head_boxes] for head_boxes in boxes]
+        """corner coordinates (normalised) -> pixels of ``target_size`` = [W, H, W, H]; the other columns pass through (semantics of
+        reference :164-176).  Heads keep their container type: an empty head stays as it is, the others become lists of rows"""
+        scale = np.asarray(target_size)
+        out = []
+        for head_boxes in boxes:
+            if len(head_boxes) == 0:
+                out.append(head_boxes)
+                continue
+            rows = np.asarray(head_boxes, dtype=np.float64).reshape(len(head_boxes), -1).copy()
+            rows[:, :4] = rows[:, :4] * scale
+            out.append(list(rows))
+        return out
 
     @staticmethod
     def visualize(image, boxes, src_box_size, image_path):
