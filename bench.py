@@ -56,7 +56,7 @@ def build_model(backbone, H, W, N, class_num, device, focal=False):
     grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
     model = YOLOv3Detector(backbone).build((H, W, 3), chans, HEAD_NAMES, batch_size=N, device=device)
     loss = YOLOv3Loss(grids, class_num, COCO_ANCHORS, 0.8, LOSS_WEIGHTS, rectified_coord_num=-1, rectified_loss_weight=[1.0, 1.0, 1.0],
-                      is_focal_loss=focal)
+                      is_focal_loss=focal, focal_alpha=1.0, focal_gamma=2.0)     # the reference's FLAGS values (configs.py:69-70)
     opt = RAdam(lr=1e-3)
     model.compile(optimizer=opt, loss=loss.loss)
     return model, loss, opt, grids

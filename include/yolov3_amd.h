@@ -276,9 +276,14 @@ int yolo_letterbox_augment(const uint8_t* src, const yolo_image_desc* desc, int 
 /* ------------------------------------------------------------------------------------------------------------------
  * RAdam + L2 regularisation over the flat parameter buffer.  Replaces RAdam.get_updates
  * (/root/reference/utils/radam.py:56-107) and the Keras L2 regularisers (/root/reference/backbone/basic_backbone.py:41,64,76).
- * sched: device float32 [4] = {lr (host-set), lr_t, rho_t, adaptive}; iterations: device int64 [1].
+ * sched: device float32 [4] = {lr (host-set), lr_t, rho_t, update rule of this step (0 first moment only = RAdam warm-up, 1 adaptive,
+ * 2 / 3 SGD momentum with / without Nesterov)}; iterations: device int64 [1].
  * ------------------------------------------------------------------------------------------------------------------ */
 int yolo_radam_schedule(float* sched, int64_t* iterations, float beta1, float beta2, float decay, float warmup_coef, void* stream);
+/* The reference trainer's two other optimizers (/root/reference/yolov3/trainer.py:70-73): kind 1 = keras Adam (amsgrad when the step gets a
+ * vhat buffer), 2 = keras SGD momentum + Nesterov (beta1 = the momentum, m = the velocity), 3 = keras SGD momentum; 0 = RAdam with
+ * warmup_coef 1.  Fills the same sched block, whose 4th word selects the update rule inside yolo_radam_l2_step. */
+int yolo_optimizer_schedule(float* sched, int64_t* iterations, int kind, float beta1, float beta2, float decay, void* stream);
 int yolo_radam_l2_blocks(int64_t n);   /* length of l2_partial */
 /* n (multiple of 256) elements; l2_table[n/256] = lambda of each 256-element chunk; grads are multiplied by grad_scale and
  * zeroed afterwards if zero_grad; params_bf16 (may be NULL) receives the bf16 copy; vhat (may be NULL) enables AMSGrad;

@@ -80,3 +80,66 @@ class RAdamOracle(object):
                 p -= np.float32(lr_t) * m_t
             self.m[i], self.v[i] = m_t, v_t
         return rho_t, lr_t
+
+
+class AdamOracle(object):
+    """keras.optimizers.Adam as the reference instantiates it at yolov3/trainer.py:72 (``Adam(lr=FLAGS.init_lr, amsgrad=True)``).  The class
+    itself lives in tensorflow (>= 1.13.1, python/keras/optimizers.py: Adam.get_updates), not under /root/reference; this restates its
+    published update:  lr' = lr / (1 + decay * iterations);  t = iterations + 1;  lr_t = lr' * sqrt(1 - b2^t) / (1 - b1^t);
+    m_t = b1 m + (1 - b1) g;  v_t = b2 v + (1 - b2) g^2;  vhat_t = max(vhat, v_t) if amsgrad;  p -= lr_t * m_t / (sqrt(vhat_t or v_t) + eps)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=None, decay=0., amsgrad=False, scalar_dtype=np.float64):
+        self.iterations, self.lr, self.beta_1, self.beta_2, self.decay = 0, lr, beta_1, beta_2, decay
+        self.epsilon = 1e-8 if epsilon is None else epsilon
+        self.amsgrad, self.sd = amsgrad, scalar_dtype
+        self.m = self.v = self.vhat = None
+
+    def step(self, params, grads):
+        f = self.sd
+        lr = f(self.lr)
+        if self.decay > 0:
+            lr = lr * (f(1.) / (f(1.) + f(self.decay) * f(self.iterations)))
+        self.iterations += 1
+        t = f(self.iterations)
+        b1s, b2s = f(np.float32(self.beta_1)), f(np.float32(self.beta_2))
+        lr_t = np.float32(lr * (np.sqrt(f(1.) - np.power(b2s, t)) / (f(1.) - np.power(b1s, t))))
+        if self.m is None:
+            self.m = [np.zeros_like(p) for p in params]
+            self.v = [np.zeros_like(p) for p in params]
+            self.vhat = [np.zeros_like(p) for p in params]
+        b1, b2, eps, one = np.float32(self.beta_1), np.float32(self.beta_2), np.float32(self.epsilon), np.float32(1.)
+        for i, (p, g) in enumerate(zip(params, grads)):
+            g = g.astype(np.float32)
+            self.m[i] = b1 * self.m[i] + (one - b1) * g
+            self.v[i] = b2 * self.v[i] + (one - b2) * np.square(g)
+            den = self.v[i]
+            if self.amsgrad:
+                self.vhat[i] = np.maximum(self.vhat[i], self.v[i])
+                den = self.vhat[i]
+            p -= lr_t * self.m[i] / (np.sqrt(den) + eps)
+        return lr_t
+
+
+class SGDOracle(object):
+    """keras.optimizers.SGD as the reference instantiates it at yolov3/trainer.py:70 (``SGD(lr=FLAGS.init_lr, momentum=0.95, nesterov=True)``);
+    tensorflow python/keras/optimizers.py SGD.get_updates restated:  lr' = lr / (1 + decay * iterations);  v = momentum * m - lr' * g;
+    m <- v;  p += momentum * v - lr' * g  (Nesterov)  or  p += v."""
+
+    def __init__(self, lr=0.01, momentum=0., decay=0., nesterov=False):
+        self.iterations, self.lr, self.momentum, self.decay, self.nesterov = 0, lr, momentum, decay, nesterov
+        self.m = None
+
+    def step(self, params, grads):
+        lr = np.float64(self.lr)
+        if self.decay > 0:
+            lr = lr * (1. / (1. + np.float64(self.decay) * self.iterations))
+        self.iterations += 1
+        lr, mom = np.float32(lr), np.float32(self.momentum)
+        if self.m is None:
+            self.m = [np.zeros_like(p) for p in params]
+        for i, (p, g) in enumerate(zip(params, grads)):
+            g = g.astype(np.float32)
+            v = mom * self.m[i] - lr * g
+            self.m[i] = v
+            p += (mom * v - lr * g) if self.nesterov else v
+        return lr

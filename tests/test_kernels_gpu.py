@@ -625,7 +625,17 @@ LOSS_CASES = [
     # duplicates in one cell + anchor, a centre exactly on the right / bottom border (floor index = W / H: clamped), a
     # centre exactly on a cell boundary, a box as large as the image and a tiny one
     dict(name='c5_edges', grid=[(16, 16), (8, 8), (4, 4)], C=5, N=4, T=6, rect=-1, focal=False, tiou=False, empty=None, edges=True),
+    # the logit of class 0 is -40 everywhere: softmax probability < eps = 1e-8, tf.clip_by_value (yolov3_decoder.py:189-191) clips it and passes
+    # no gradient, so a target of class 0 costs -log(eps) and moves no class logit, while the other targets of the same cell + anchor still do
+    dict(name='c6_saturated_class', grid=[(16, 16), (8, 8), (4, 4)], C=6, N=3, T=6, rect=-1, focal=False, tiou=False, empty=None, saturate=True),
 ]
+
+
+def test_loss_focal_through_the_fp16_library(dev, fp16):
+    """BASELINE.json configs[4]: the focal + TIoU case through libyolov3_amd_fp16.so with the static loss scale 1024 -- the float32 terms and
+    d(logits) are unscaled, the float16 copy that feeds the backward pass is exactly fp16(1024 * d(logits))"""
+    case = dict([c for c in LOSS_CASES if c['name'] == 'c20_focal_tiou'][0], grad_scale16=1024.0)
+    test_loss_fwd_bwd_vs_oracle(dev, case)
 
 
 @pytest.mark.parametrize('case', LOSS_CASES, ids=[c['name'] for c in LOSS_CASES])
@@ -641,6 +651,12 @@ def test_loss_fwd_bwd_vs_oracle(dev, case):
     ldc = [ops.pad_channels(b * L) for b in B]
     raw = [torch.randn(N, h, w, b, L, generator=gen) * 0.8 for (h, w), b in zip(grid, B)]
     lab = make_labels(gen, N, T, Cn, case['empty'])
+    if case.get('saturate'):
+        for r in raw:
+            r[..., 5] = -40.0
+        lab[:, 0::2, 4] = torch.where(lab[:, 0::2, 4] >= 0, torch.zeros(()), lab[:, 0::2, 4])      # every other target is of class 0
+        lab[1, 1] = lab[1, 0]
+        lab[1, 1, 4] = 3.0                                                                        # same box, classes 0 and 3: one clipped, one live
     if case.get('edges'):
         lab[0, :3] = torch.tensor([[0.40, 0.55, 0.30, 0.20, 2.0], [0.40, 0.55, 0.30, 0.20, 2.0], [0.41, 0.56, 0.30, 0.20, 3.0]])
         lab[1, :2] = torch.tensor([[1.0, 1.0, 0.20, 0.30, 1.0], [0.5, 0.25, 0.10, 0.10, 0.0]])      # border; exact cell boundary at every head
@@ -657,7 +673,7 @@ def test_loss_fwd_bwd_vs_oracle(dev, case):
 
     cfg = ops.make_loss_config(grid, Cn, ANCHORS, 0.5, LOSS_W, ldc, T, rectified_coord_num=case['rect'],
                                rectified_loss_weight=[1.0, 0.5, 2.0], is_focal_loss=case['focal'], focal_alpha=1.0, focal_gamma=2.0,
-                               is_tiou_recall=case['tiou'])
+                               is_tiou_recall=case['tiou'], grad_scale16=case.get('grad_scale16', 1.0))
     logits, dl, dlb = [], [], []
     for h in range(3):
         gh, gw = grid[h]
@@ -709,7 +725,7 @@ def test_loss_fwd_bwd_vs_oracle(dev, case):
             assert torch.equal(torch.isnan(got[..., :B[h] * L]), torch.isnan(gref))
             denom = torch.nan_to_num(gref).abs().max().item()
         torch.testing.assert_close(got[..., :B[h] * L], gref, rtol=1e-3, atol=1e-5 * max(denom, 1.0), equal_nan=nan_ok)
-        torch.testing.assert_close(dlb[h].float().cpu(), got.to(ACT()).float(), rtol=0, atol=0, equal_nan=nan_ok)
+        torch.testing.assert_close(dlb[h].float().cpu(), (got * case.get('grad_scale16', 1.0)).to(ACT()).float(), rtol=0, atol=0, equal_nan=nan_ok)
     # second call: counter advanced -> rectified term switches off when current_num > rectified_coord_num
     ops.loss_fwd_bwd(cfg, N, N, logits, lab.to(dev), cur, terms, total, ws, dlogits=dl)
     total2 = orc.loss_heads(lab.reshape(N, -1), [r.clone() for r in raw])
@@ -756,6 +772,50 @@ def test_radam_l2_step_vs_oracle(dev):
         np.testing.assert_allclose(l2out.cpu().numpy()[0], l2_ref, rtol=1e-5)
         assert torch.count_nonzero(gd) == 0
         assert torch.equal(pb.cpu(), p.cpu().to(ACT()))
+
+
+@pytest.mark.parametrize('kind', ['radam_amsgrad_decay', 'adam_amsgrad', 'adam_decay', 'sgd_nesterov', 'sgd_momentum_decay'])
+def test_optimizer_variants_vs_oracle(dev, kind):
+    """the branches of the multi-tensor kernel the default RAdam(lr=1e-3) does not take: RAdam's AMSGrad / decay (radam.py:61-64,91-94) and the
+    reference trainer's other two optimizers, keras SGD(momentum=0.95, nesterov=True) and Adam(amsgrad=True) (trainer.py:70-73), 12 steps
+    each against oracle/optim.py with gradients whose magnitude falls after step 4 (so vhat != v); L2 on one segment."""
+    from yolov3_tensorflow_amd import ops
+    from oracle.optim import RAdamOracle, AdamOracle, SGDOracle
+    rng = np.random.default_rng(1)
+    n = 1024
+    p0 = rng.normal(size=n).astype(np.float32)
+    lam = np.zeros(n // 256, dtype=np.float32)
+    lam[1] = 5e-4
+    lam_e = np.repeat(lam, 256)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    if kind == 'radam_amsgrad_decay':
+        orc, k, b1, b2, eps, decay, ams = RAdamOracle(lr=1e-3, decay=0.05, amsgrad=True, scalar_dtype=np.float64), 0, 0.9, 0.999, 1e-8, 0.05, True
+    elif kind == 'adam_amsgrad':
+        orc, k, b1, b2, eps, decay, ams = AdamOracle(lr=2e-4, amsgrad=True), 1, 0.9, 0.999, 1e-8, 0.0, True
+    elif kind == 'adam_decay':
+        orc, k, b1, b2, eps, decay, ams = AdamOracle(lr=2e-4, decay=0.1), 1, 0.9, 0.999, 1e-8, 0.1, False
+    elif kind == 'sgd_nesterov':
+        orc, k, b1, b2, eps, decay, ams = SGDOracle(lr=2e-4, momentum=0.95, nesterov=True), 2, 0.95, 0.0, 0.0, 0.0, False
+    else:
+        orc, k, b1, b2, eps, decay, ams = SGDOracle(lr=2e-4, momentum=0.9, decay=0.1), 3, 0.9, 0.0, 0.0, 0.1, False
+    pr = p0.copy()
+    p, m, v = d(p0.copy()), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    vhat = torch.zeros(n, device=dev) if ams else None
+    sched = torch.tensor([orc.lr, 0, 0, 0], device=dev, dtype=torch.float32)
+    it = torch.zeros(1, dtype=torch.int64, device=dev)
+    for step in range(12):
+        g = (rng.normal(size=n) * (1.0 if step < 4 else 0.1)).astype(np.float32)
+        orc.step([pr], [g + 2 * lam_e * pr])
+        if k == 0:
+            ops.radam_schedule(sched, it, b1, b2, decay, 1.0)
+        else:
+            ops.optimizer_schedule(sched, it, k, b1, b2, decay)
+        ops.radam_l2_step(p, d(g.copy()), m, v, d(lam), n, sched, b1, b2, eps, 1.0, True, vhat=vhat)
+        assert int(it.cpu()[0]) == step + 1
+        np.testing.assert_allclose(p.cpu().numpy(), pr, rtol=1e-5, atol=1e-6, err_msg='%s step %d' % (kind, step))
+    if ams:
+        np.testing.assert_allclose(vhat.cpu().numpy(), orc.vhat[0], rtol=1e-5, atol=1e-12)
+        assert (vhat.cpu().numpy() > v.cpu().numpy()).mean() > 0.5          # the maximum was the live branch
 
 
 def test_radam_skips_and_counts_nonfinite_gradients(dev):

@@ -84,3 +84,45 @@ def test_single_process_is_a_noop(monkeypatch):
     monkeypatch.delenv('WORLD_SIZE', raising=False)
     m = _FakeModel(256, 0)
     assert parallel.setup_data_parallel(m) is False and m.world_size == 1
+
+
+def _agree_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank))
+    from yolov3_tensorflow_amd import parallel
+    dist.init_process_group('gloo')
+    # the ranks see different shards, hence different epoch losses: rank 1's own loss stops improving at epoch 2, rank 0's never does
+    own = [[10.0, 9.0, 8.0, 7.0, 6.0, 5.0], [10.0, 9.0, 9.5, 9.5, 9.5, 9.5]][rank]
+    local, agreed = parallel.EarlyStopping(1e-4, 2), parallel.EarlyStopping(1e-4, 2)
+    local_stop = agreed_stop = None
+    means = []
+    for epoch, loss in enumerate(own):
+        if local_stop is None and local.should_stop(loss):
+            local_stop = epoch
+        mean = parallel.agree_mean(loss)
+        means.append(mean)
+        if agreed_stop is None and agreed.should_stop(mean):
+            agreed_stop = epoch
+    failure = parallel.agree_any(rank == 1)                       # only rank 1 hit a device-protocol error
+    nofail = parallel.agree_any(False)
+    out[rank] = (local_stop, agreed_stop, means, failure, nofail)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_early_stopping_and_failures():
+    """every rank must take the same early-stopping decision and leave together on a failure, or the others hang in the next all-reduce"""
+    world, port = 2, 29741
+    out = mp.Manager().dict()
+    mp.spawn(_agree_worker, args=(world, port, out), nprocs=world, join=True)
+    (l0, a0, m0, f0, n0), (l1, a1, m1, f1, n1) = out[0], out[1]
+    assert l0 != l1                                               # decided locally the ranks would diverge ...
+    assert a0 == a1 and m0 == m1                                  # ... on the agreed mean they do not
+    np.testing.assert_allclose(m0, [10.0, 9.0, 8.75, 8.25, 7.75, 7.25])
+    assert f0 is True and f1 is True and n0 is False and n1 is False
+
+
+def test_per_rank_batch_is_the_global_batch_divided():
+    from yolov3_tensorflow_amd import parallel
+    assert parallel.per_rank_batch(256, 8) == 32 and parallel.per_rank_batch(3, 1) == 3
+    with pytest.raises(ValueError):
+        parallel.per_rank_batch(3, 2)

@@ -135,3 +135,31 @@ def test_product_nms_matches_oracle_on_adversarial_rows(seed):
     size = np.array([480, 384, 480, 384])
     for w, g in zip(pp.resize_boxes(want, size), P.resize_boxes(got, size)):
         np.testing.assert_array_equal(np.asarray(g, dtype=np.float64).reshape(-1, 9), np.asarray(w, dtype=np.float64).reshape(-1, 9))
+
+
+def test_data_parallel_ranks_read_disjoint_slices_of_the_single_process_batches(tmp_path):
+    """two ranks with per-rank batch 2 == one process with batch 4 (keras multi_gpu_model splits the one batch on axis 0, reference
+    trainer.py:40-43): every global batch is covered exactly once, the ranks' slices are disjoint, and images, labels AND augmentation
+    draws concatenate to what the single process sees"""
+    from PIL import Image
+    from yolov3_tensorflow_amd.dataset.file_util import FileUtil
+    rng = np.random.default_rng(1)
+    lines = []
+    for i in range(9):
+        Image.fromarray(rng.integers(0, 255, (32 + 2 * i, 48, 3), dtype=np.uint8)).save(tmp_path / ('%d.jpg' % i))
+        lines.append('%d.jpg 0.5 0.5 0.2 0.2 %d' % (i, i))
+    label = str(tmp_path / 'label.txt')
+    (tmp_path / 'label.txt').write_text('\n'.join(lines) + '\n')
+    single = FileUtil.host_batches(label, str(tmp_path), (64, 64), 4, is_augment=True)
+    ranks = [FileUtil.host_batches(label, str(tmp_path), (64, 64), 2, is_augment=True, rank=r, world=2) for r in range(2)]
+    for step in range(5):                                                   # 2 global batches per epoch of 9 images: crosses two reshuffles
+        imgs, y, draws, paths = next(single)
+        parts = [next(it) for it in ranks]
+        assert not set(parts[0][3]) & set(parts[1][3])                      # disjoint
+        assert parts[0][3] + parts[1][3] == paths                           # together: the single-process batch, in its order
+        np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), y)
+        assert parts[0][2] + parts[1][2] == draws
+        for a, b in zip(parts[0][0] + parts[1][0], imgs):
+            np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        next(FileUtil.host_batches(label, str(tmp_path), (64, 64), 2, rank=2, world=2))

@@ -32,7 +32,7 @@ def make_batch(N, H, W, T, class_num, seed):
     return images, labels.reshape(N, T * 5)
 
 
-def build(backbone, H, W, N, class_num, rect):
+def build(backbone, H, W, N, class_num, rect, focal=False):
     from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
     from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
     from yolov3_tensorflow_amd.utils.radam import RAdam
@@ -40,7 +40,9 @@ def build(backbone, H, W, N, class_num, rect):
     chans = [len(a) * L for a in ANCHORS]
     grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
     model = YOLOv3Detector(backbone).build((H, W, 3), chans, NAMES, batch_size=N)
-    loss = YOLOv3Loss(grids, class_num, ANCHORS, 0.5, LOSS_W, rectified_coord_num=rect, rectified_loss_weight=[1.0, 1.0, 1.0])
+    # focal: the reference's FLAGS values alpha 1, gamma 2 (configs.py:69-70), BASELINE.json configs[4]
+    loss = YOLOv3Loss(grids, class_num, ANCHORS, 0.5, LOSS_W, rectified_coord_num=rect, rectified_loss_weight=[1.0, 1.0, 1.0],
+                      is_focal_loss=focal, focal_alpha=1.0, focal_gamma=2.0)
     opt = RAdam(lr=1e-3)
     model.compile(optimizer=opt, loss=loss.loss)
     return model, loss, opt, grids
@@ -59,11 +61,14 @@ def compute_dtype(request):
     backend.set_compute_dtype('bfloat16')
 
 
-@pytest.mark.parametrize('backbone,rect,compute_dtype', [('resnet-18', -1, 'bfloat16'), ('resnet-18', 1464, 'bfloat16'),
-                                                         ('resnet-18-v2', -1, 'bfloat16'), ('mixnet-18', -1, 'bfloat16'),
-                                                         ('resnet-18-v2', -1, 'float16'), ('resnet-18', 1464, 'float16'),
-                                                         ('mixnet-18', -1, 'float16')], indirect=['compute_dtype'])
-def test_forward_loss_grads_and_step(backbone, rect, compute_dtype):
+@pytest.mark.parametrize('backbone,rect,compute_dtype,focal',
+                         [('resnet-18', -1, 'bfloat16', False), ('resnet-18', 1464, 'bfloat16', False),
+                          ('resnet-18-v2', -1, 'bfloat16', False), ('mixnet-18', -1, 'bfloat16', False),
+                          ('resnet-18-v2', -1, 'float16', False), ('resnet-18', 1464, 'float16', False),
+                          ('mixnet-18', -1, 'float16', False),
+                          ('resnet-18-v2', -1, 'float16', True),       # BASELINE.json configs[4]: ResNet18-v2, fp16 build, focal loss on
+                          ('resnet-18', -1, 'bfloat16', True)], indirect=['compute_dtype'])
+def test_forward_loss_grads_and_step(backbone, rect, compute_dtype, focal):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from oracle.train import OracleTrainer
@@ -76,15 +81,16 @@ def test_forward_loss_grads_and_step(backbone, rect, compute_dtype):
     # bf16-forward gradients differ by 50 % -- nothing can be checked there
     H = W = 224
     N, T, Cn = 4, 4, 13
-    model, loss, opt, grids = build(backbone, H, W, N, Cn, rect=rect)
+    model, loss, opt, grids = build(backbone, H, W, N, Cn, rect=rect, focal=focal)
     images, labels = make_batch(N, H, W, T, Cn, seed=3)
     w0 = model.get_weights()
     model.use_hip_graph = False
+    fk = dict(is_focal_loss=focal, focal_alpha=1.0, focal_gamma=2.0)
 
     orc = {}
     for tag, emu, emug in (('f32', False, False), ('bf16', 'float16' if half else True, False)):
         o = OracleTrainer(backbone, grids, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=rect, rectified_loss_weight=[1.0, 1.0, 1.0],
-                          emulate_bf16=emu, emulate_bf16_grads=emug)
+                          emulate_bf16=emu, emulate_bf16_grads=emug, **fk)
         o.ensure_params(images)
         assert list(o.det.params.p.keys()) == list(w0.keys()) or set(o.det.params.p.keys()) == set(w0.keys())
         o.set_weights(w0)
@@ -116,7 +122,7 @@ def test_forward_loss_grads_and_step(backbone, rect, compute_dtype):
     assert abs(loss_gpu - res['f32'][1]) <= 2e-2 * abs(res['f32'][1]), (loss_gpu, res['f32'][1])
     # the loss kernel on the GPU's own logits must agree with the oracle loss on those logits to float32 accuracy
     raw = [h.reshape(N, h.shape[1], h.shape[2], len(a), 5 + Cn) for h, a in zip(heads_gpu, ANCHORS)]
-    chk = OracleTrainer(backbone, grids, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=rect, rectified_loss_weight=[1.0, 1.0, 1.0])
+    chk = OracleTrainer(backbone, grids, Cn, ANCHORS, 0.5, LOSS_W, rectified_coord_num=rect, rectified_loss_weight=[1.0, 1.0, 1.0], **fk)
     lchk = float(chk.loss.loss_heads(torch.as_tensor(labels), raw).item())
     assert abs(loss_gpu - lchk) <= 1e-4 * abs(lchk)
 

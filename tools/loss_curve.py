@@ -1,55 +1,88 @@
 #!/usr/bin/env python
-"""Loss curve of BASELINE.json configs[0] (ResNet18-YOLOv3 320x320, the reference's 20-image sample set, batch 2, 13 classes, the
-reference's first-epoch learning rate 1e-5): the GPU path against the float32 CPU oracle, same initial weights, same batches, step by
-step.  Writes a JSON summary (north_star: loss within 1e-3 of the reference run).
-Usage: python tools/loss_curve.py [--steps 20] [--out profiles/r01_loss_curve_config1.json]"""
+"""Loss curve of BASELINE.json configs[0] (ResNet18-YOLOv3 320x320, the reference's 20-image sample set, batch 2, 13 classes): the GPU path
+against the float32 CPU oracle AND the oracle that emulates the product's 16-bit storage points, same initial weights, same batches, step
+by step.  The first ``--plateau-after`` steps run at the reference's first-epoch learning rate 1e-5 (RAdam's rho_t < 5 warm-up happens
+there: steps 1-5), the rest at its plateau rate 1e-3 (configs.py:16-17).  Writes a JSON summary (north_star: loss within 1e-3 of the
+reference run).
+Usage: python tools/loss_curve.py [--steps 20] [--plateau-after 10] [--dtype bfloat16] [--out profiles/r02_loss_curve_config1.json]"""
 import argparse, json, os, sys
 import numpy as np
-import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from test_config1_gpu import load_fixture
-from yolov3_tensorflow_amd.configs import FLAGS
-from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
-from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
-from yolov3_tensorflow_amd.utils.radam import RAdam
-from oracle.train import OracleTrainer
 
-ap = argparse.ArgumentParser()
-ap.add_argument('--steps', type=int, default=20)
-ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float16'])
-ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'loss_curve_config1.json'))
-a = ap.parse_args()
-from yolov3_tensorflow_amd import backend
-backend.set_compute_dtype(a.dtype)
-images, labels = load_fixture()
-H = W = 320
-N, Cn = 2, 13
-anchors, lw = FLAGS.anchor_boxes, FLAGS.loss_weights
-chans = [len(b) * (5 + Cn) for b in anchors]
-grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
-model = YOLOv3Detector('resnet-18').build((H, W, 3), chans, FLAGS.head_names, batch_size=N)
-loss = YOLOv3Loss(grids, Cn, anchors, FLAGS.iou_thresh, lw, rectified_coord_num=FLAGS.rectified_coord_num,
-                  rectified_loss_weight=FLAGS.rectified_loss_weight)
-opt = RAdam(lr=1e-3)
-model.compile(optimizer=opt, loss=loss.loss)
-opt.lr = 1e-5
-o = OracleTrainer('resnet-18', grids, Cn, anchors, FLAGS.iou_thresh, lw, rectified_coord_num=FLAGS.rectified_coord_num,
-                  rectified_loss_weight=FLAGS.rectified_loss_weight, lr=1e-5)
-o.ensure_params(images[:N])
-o.set_weights(model.get_weights())
-gpu, ref = [], []
-for step in range(a.steps):
-    i = (step * N) % 20
-    x, y = images[i:i + N], labels[i:i + N]
-    gpu.append(float(model.train_on_batch(x, y)))
-    ref.append(float(o.step(x, y)[0]))
-    print('step %2d  gpu %.4f  oracle %.4f  rel %.2e' % (step + 1, gpu[-1], ref[-1], abs(gpu[-1] - ref[-1]) / abs(ref[-1])), flush=True)
-rel = [abs(g - r) / abs(r) for g, r in zip(gpu, ref)]
-out = {'config': 'ResNet18-YOLOv3 320x320, reference sample set (20 images), batch 2, 13 classes, lr 1e-5, %s GPU path vs float32 CPU oracle' % a.dtype,
-       'steps': a.steps, 'gpu_loss': gpu, 'oracle_loss': ref, 'relative_deviation': rel, 'max_relative_deviation': max(rel),
-       'median_relative_deviation': float(np.median(rel))}
-os.makedirs(os.path.dirname(a.out), exist_ok=True)
-json.dump(out, open(a.out, 'w'), indent=1)
-print('max rel %.2e  median %.2e' % (max(rel), float(np.median(rel))))
+
+def load_fixture():
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'sample20_320.npz'))
+    images = (z['images_rgb_u8'].astype(np.float32) / 255.0)[..., ::-1].copy()        # /255, RGB -> BGR (file_util.py:58-59)
+    return images, z['labels']
+
+
+def run(steps=20, plateau_after=10, dtype='bfloat16', with_emulating_oracle=True, verbose=True):
+    from yolov3_tensorflow_amd import backend
+    from yolov3_tensorflow_amd.configs import FLAGS
+    from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
+    from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
+    from yolov3_tensorflow_amd.utils.radam import RAdam
+    from oracle.train import OracleTrainer
+    backend.set_compute_dtype(dtype)
+    try:
+        images, labels = load_fixture()
+        H = W = 320
+        N, Cn = 2, 13
+        anchors, lw = FLAGS.anchor_boxes, FLAGS.loss_weights
+        chans = [len(b) * (5 + Cn) for b in anchors]
+        grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+        model = YOLOv3Detector('resnet-18').build((H, W, 3), chans, FLAGS.head_names, batch_size=N)
+        loss = YOLOv3Loss(grids, Cn, anchors, FLAGS.iou_thresh, lw, rectified_coord_num=FLAGS.rectified_coord_num,
+                          rectified_loss_weight=FLAGS.rectified_loss_weight)
+        opt = RAdam(lr=1e-3)
+        model.compile(optimizer=opt, loss=loss.loss)
+        oracles = {'float32': False}
+        if with_emulating_oracle:
+            oracles['emulating'] = 'float16' if backend.compute_dtype() == 'float16' else True
+        orc = {}
+        for tag, emu in oracles.items():
+            o = OracleTrainer('resnet-18', grids, Cn, anchors, FLAGS.iou_thresh, lw, rectified_coord_num=FLAGS.rectified_coord_num,
+                              rectified_loss_weight=FLAGS.rectified_loss_weight, lr=1e-5, emulate_bf16=emu)
+            o.ensure_params(images[:N])
+            o.set_weights(model.get_weights())
+            orc[tag] = o
+        gpu, ref = [], {t: [] for t in orc}
+        for step in range(steps):
+            lr = 1e-5 if step < plateau_after else 1e-3
+            opt.lr = lr
+            i = (step * N) % 20
+            x, y = images[i:i + N], labels[i:i + N]
+            gpu.append(float(model.train_on_batch(x, y)))
+            for t, o in orc.items():
+                o.opt.lr = lr
+                ref[t].append(float(o.step(x, y)[0]))
+            if verbose:
+                print('step %2d lr %.0e  gpu %.4f  ' % (step + 1, lr, gpu[-1]) +
+                      '  '.join('%s %.4f (rel %.2e)' % (t, v[-1], abs(gpu[-1] - v[-1]) / abs(v[-1])) for t, v in ref.items()), flush=True)
+        model.check_device_protocols()
+    finally:
+        backend.set_compute_dtype('bfloat16')
+    out = {'config': 'ResNet18-YOLOv3 320x320, reference sample set (20 images), batch 2, 13 classes, lr 1e-5 for %d steps then 1e-3, %s GPU path'
+                     % (min(plateau_after, steps), dtype), 'steps': steps, 'plateau_after': plateau_after, 'gpu_loss': gpu}
+    for t, v in ref.items():
+        rel = [abs(g - r) / abs(r) for g, r in zip(gpu, v)]
+        out[t + '_oracle'] = {'loss': v, 'relative_deviation': rel, 'max': max(rel), 'median': float(np.median(rel)),
+                              'steps_within_1e-3': int(sum(r <= 1e-3 for r in rel))}
+    return out
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--plateau-after', type=int, default=10)
+    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float16'])
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'loss_curve_config1.json'))
+    a = ap.parse_args()
+    out = run(a.steps, a.plateau_after, a.dtype)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(out, open(a.out, 'w'), indent=1)
+    for t in ('float32', 'emulating'):
+        if t + '_oracle' in out:
+            print('%s oracle: max rel %.2e  median %.2e  within 1e-3: %d / %d' % (t, out[t + '_oracle']['max'], out[t + '_oracle']['median'],
+                                                                                  out[t + '_oracle']['steps_within_1e-3'], a.steps))

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""The reference's own default run (configs.py:31-61 untouched: ResNet18-YOLOv3, 384x480, class_num 0, batch 3, 7 steps / epoch, RAdam
+under lr_func, rectified_coord_num 1464, augmentation on, 300 epochs over the 20 sample images of dataset/test_sample) through this
+package's run.train, i.e. JPEG decode -> GPU letterbox + augmentation -> training step -> callbacks.
+
+The only numbers the reference holds for this path are on its TensorBoard screenshot images/tensorboard_loss.jpg (README.md:30): at epoch
+218 the Keras loss is 16.2 (smoothed 16.69) and the last-step terms are head /8 noobj 4.381, obj 2.823, wh 2.71, xy 1.25; head /16 noobj
+0.5648, obj 0.0381, wh 0.0079, xy 0.0064; head /32 noobj 0.5378, obj 0.0383, wh 0.8221, xy 0.0227 (sum 13.2; the rest is the L2 term).
+This is a SANITY pin of the whole path (same config, same data files, a different random stream: TensorFlow's initialiser, shuffle and
+augmentation draws cannot be reproduced), not bit parity.  Writes the curve as JSON.
+Usage: python tools/reference_default_run.py [--epochs 300] [--out profiles/r02_reference_default_run.json] [--dtype bfloat16]"""
+import argparse, json, os, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SCREENSHOT_EPOCH = 218
+SCREENSHOT = {'loss': 16.2, 'loss_smoothed': 16.69,
+              'head_8': {'noobj': 4.381, 'obj': 2.823, 'wh': 2.71, 'xy': 1.25},
+              'head_16': {'noobj': 0.5648, 'obj': 0.03811, 'wh': 7.9058e-3, 'xy': 6.3541e-3},
+              'head_32': {'noobj': 0.5378, 'obj': 0.0383, 'wh': 0.8221, 'xy': 0.0227}}
+ROWS = ('xy', 'wh', 'noobj', 'obj', 'class', 'rectified')
+
+
+def run(epochs=300, dtype='bfloat16', seed=800, workdir=None, sample_dir=None):
+    """-> history dict of YOLOv3Trainer.train (loss / lr / terms per epoch)"""
+    from yolov3_tensorflow_amd import backend, configs
+    backend.set_compute_dtype(dtype)
+    F = configs.FLAGS
+    saved = dict(F)
+    sample_dir = sample_dir or os.path.join(ROOT, 'tests', 'golden', 'test_sample')
+    workdir = workdir or tempfile.mkdtemp(prefix='yolo_default_run_')
+    try:
+        F.update(configs.DEFAULTS)                              # the reference's defaults, nothing else
+        F.train_set_dir = F.test_set_dir = os.path.join(sample_dir, 'images')
+        F.train_label_path = F.test_label_path = os.path.join(sample_dir, 'label.txt')
+        F.root_path = workdir + os.sep
+        F.epoch = int(epochs)
+        configs.refresh_derived()
+        from yolov3_tensorflow_amd import run as run_mod
+        from yolov3_tensorflow_amd.yolov3.trainer import YOLOv3Trainer
+        trainer = YOLOv3Trainer()
+        run_mod.train(trainer)
+        return trainer.history
+    finally:
+        F.clear()
+        F.update(saved)
+        backend.set_compute_dtype('bfloat16')
+
+
+def summarise(history):
+    loss = [float(v) for v in history['loss']]
+    terms = np.stack(history['terms'])                          # (epochs, 6, 3)
+    e = min(SCREENSHOT_EPOCH, len(loss)) - 1                    # TensorBoard step 218 = Keras epoch index 218 (0-based 217..218): use a window
+    lo, hi = max(0, e - 10), min(len(loss), e + 11)
+    win = {'epochs': [lo, hi], 'loss_mean': float(np.mean(loss[lo:hi])), 'loss_min': float(np.min(loss[lo:hi])), 'loss_max': float(np.max(loss[lo:hi]))}
+    for h, name in enumerate(('head_8', 'head_16', 'head_32')):
+        win[name] = {ROWS[k]: float(terms[lo:hi, k, h].mean()) for k in range(6)}
+    # TensorBoard's smoothing (exponential moving average, weight 0.6, debiased) of the loss curve up to the screenshot's step
+    ema, s = [], 0.0
+    for i, v in enumerate(loss):
+        s = 0.6 * s + 0.4 * v
+        ema.append(s / (1 - 0.6 ** (i + 1)))
+    return {'loss': loss, 'lr': [float(v) for v in history['lr']], 'loss_smoothed_0.6': ema,
+            'terms_rows': list(ROWS), 'terms_last_step_of_epoch': terms.tolist(), 'window_around_epoch_218': win, 'screenshot': SCREENSHOT}
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--epochs', type=int, default=300)
+    ap.add_argument('--dtype', default='bfloat16')
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'reference_default_run.json'))
+    a = ap.parse_args()
+    import logging
+    logging.basicConfig(level=logging.WARNING)
+    out = summarise(run(a.epochs, a.dtype))
+    out['config'] = 'reference defaults (configs.py:31-61): resnet-18, 384x480, class_num 0, batch 3, 7 steps/epoch, radam + lr_func, augmentation on, %s' % a.dtype
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(out, open(a.out, 'w'))
+    w = out['window_around_epoch_218']
+    print('epochs %d  loss[0] %.2f  loss[-1] %.2f' % (len(out['loss']), out['loss'][0], out['loss'][-1]))
+    print('window %s: loss mean %.2f (min %.2f max %.2f)  screenshot 16.2' % (w['epochs'], w['loss_mean'], w['loss_min'], w['loss_max']))
+    for h in ('head_8', 'head_16', 'head_32'):
+        print(h, {k: round(v, 4) for k, v in w[h].items()}, 'screenshot', SCREENSHOT[h])

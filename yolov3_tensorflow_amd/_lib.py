@@ -92,6 +92,7 @@ SIGNATURES = {
     'yolo_letterbox_workspace_bytes': (I64, [I]),
     'yolo_letterbox_augment': (I, [P, P, I, I, I, I, P, P, P, P]),
     'yolo_radam_schedule': (I, [P, P, F, F, F, F, P]),
+    'yolo_optimizer_schedule': (I, [P, P, I, F, F, F, P]),
     'yolo_radam_l2_blocks': (I, [I64]),
     'yolo_radam_l2_step': (I, [P, P, P, P, P, P, P, I64, P, F, F, F, F, I, P, P, P]),
     'yolo_cast_f32_to_bf16': (I, [P, P, I64, P]),

@@ -250,9 +250,10 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
           if (s_as[k] != pid) continue;
           const int cls = s_cls[k];
           if (cls >= 0 && cls < C) {
-            acc[4] += -logf(clipf_(expf(t[5 + cls] - mx) / se, eps_lo, eps_hi));
-            ++nv;
-          }
+            const float pc = expf(t[5 + cls] - mx) / se;
+            acc[4] += -logf(clipf_(pc, eps_lo, eps_hi));
+            if (pc >= eps_lo && pc <= eps_hi) ++nv;            // tf.clip_by_value (yolov3_decoder.py:191) passes no gradient once the target's
+          }                                                    // probability is clipped: that target then moves none of the class logits
         }
         nvalid = (float)nv;
       }
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
             const int rpid = (cell_base + clx) * B + bb;
             const float sm = expf(lg[(size_t)(cell_base + clx) * ldc + ch] - s_w[pl * 8 + 5]) / s_w[pl * 8 + 6];
             float cnt = 0.f;
-            for (int t2 = 0; t2 < T; ++t2) cnt += (s_as[t2] == rpid && s_cls[t2] == k) ? 1.f : 0.f;
+            if (sm >= eps_lo && sm <= eps_hi)                // targets of class k whose (this) probability is not clipped
+              for (int t2 = 0; t2 < T; ++t2) cnt += (s_as[t2] == rpid && s_cls[t2] == k) ? 1.f : 0.f;
             v[u] = gscale * (s_w[pl * 8 + 7] * sm - cnt);
           }
         }

@@ -10,11 +10,27 @@
 namespace {
 
 // schedule state in device memory (graph-capturable: no host scalar changes between replays)
-//   f[0] = lr (set by the host when the epoch schedule changes), f[1] = lr_t, f[2] = rho_t, f[3] = adaptive (1.0 / 0.0)
+//   f[0] = lr (set by the host when the epoch schedule changes), f[1] = lr_t, f[2] = rho_t,
+//   f[3] = update rule of this step: 0 plain first moment (RAdam warm-up), 1 adaptive (RAdam rho_t >= 5, Adam), 2 SGD momentum + Nesterov, 3 SGD momentum
 //   it[0] = iterations (int64)
-__global__ void radam_schedule_kernel(float* __restrict__ f, long long* __restrict__ it, float beta1, float beta2, float decay,
+// kind: 0 = RAdam (utils/radam.py:56-107); 1 = keras Adam, 2 / 3 = keras SGD with / without Nesterov momentum -- the two other optimizers the
+// reference trainer can select (yolov3/trainer.py:70-73: SGD(momentum=0.95, nesterov=True), Adam(amsgrad=True)).  Their update rules are
+// tf.keras' (tensorflow 1.13.1, python/keras/optimizers.py SGD.get_updates / Adam.get_updates; not part of /root/reference):
+//   SGD:  lr' = lr / (1 + decay * iterations);  v = momentum * m - lr' * g;  m <- v;  p += nesterov ? momentum * v - lr' * g : v
+//   Adam: t = iterations + 1;  lr_t = lr' * sqrt(1 - b2^t) / (1 - b1^t);  m, v as RAdam;  p -= lr_t * m / (sqrt(amsgrad ? max(vhat, v) : v) + eps)
+__global__ void radam_schedule_kernel(float* __restrict__ f, long long* __restrict__ it, int kind, float beta1, float beta2, float decay,
                                       float warmup_coef) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (kind != 0) {
+    double lr = (double)f[0];
+    if (decay > 0.f) lr = lr * (1.0 / (1.0 + (double)decay * (double)it[0]));
+    it[0] += 1;
+    const double t = (double)it[0];
+    f[1] = kind == 1 ? (float)(lr * (sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)))) : (float)lr;
+    f[2] = 0.f;
+    f[3] = (float)kind;
+    return;
+  }
   // The reference evaluates this scalar chain in float32 (K.floatx()); there 1 - beta_2^t cancels catastrophically for small t
   // (rho_t = rho_inf - 2t*b2^t/(1-b2^t) is a difference of two ~2e3 numbers), so float32 results differ by up to ~1 % between
   // pow() implementations.  We evaluate in double -- the value every float32 implementation approximates -- and round once.
@@ -45,7 +61,8 @@ __global__ __launch_bounds__(OPT_THREADS) void radam_l2_kernel(float* __restrict
                                                                float beta1, float beta2, float eps, float grad_scale, int zero_grad,
                                                                float* __restrict__ l2_partial, int* __restrict__ nonfinite) {
   const float lr_t = sched[1];
-  const bool adaptive = sched[3] != 0.f;
+  const int rule = (int)sched[3];
+  const bool adaptive = rule == 1;
   float l2acc = 0.f;
   bool bad = false;
   for (size_t i = (size_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * OPT_THREADS) {
@@ -62,6 +79,12 @@ __global__ __launch_bounds__(OPT_THREADS) void radam_l2_kernel(float* __restrict
       l2acc += lam * pp[j] * pp[j];
       if (nonfinite && !__builtin_isfinite(gg[j])) { gg[j] = 0.f; bad = true; }   // an overflowed (fp16) / NaN gradient element: not applied, counted
       const float gr = gg[j] * grad_scale + 2.f * lam * pp[j];
+      if (rule >= 2) {                                               // keras SGD: beta1 is the momentum, m the velocity
+        const float vel = beta1 * mm[j] - lr_t * gr;
+        mm[j] = vel;
+        pp[j] = rule == 2 ? pp[j] + beta1 * vel - lr_t * gr : pp[j] + vel;
+        continue;
+      }
       mm[j] = beta1 * mm[j] + (1.f - beta1) * gr;                    // radam.py:88
       vv[j] = beta2 * vv[j] + (1.f - beta2) * (gr * gr);             // radam.py:89
       float den = vv[j];
@@ -121,8 +144,17 @@ inline int opt_grid(size_t n4) {
 
 extern "C" int yolo_radam_schedule(float* sched, int64_t* iterations, float beta1, float beta2, float decay, float warmup_coef, void* stream) {
   YOLO_CHECK_ARG(sched && iterations, "null pointer");
-  hipLaunchKernelGGL(radam_schedule_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sched, (long long*)iterations, beta1, beta2, decay,
+  hipLaunchKernelGGL(radam_schedule_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sched, (long long*)iterations, 0, beta1, beta2, decay,
                      warmup_coef);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_optimizer_schedule(float* sched, int64_t* iterations, int kind, float beta1, float beta2, float decay, void* stream) {
+  YOLO_CHECK_ARG(sched && iterations, "null pointer");
+  YOLO_CHECK_ARG(kind >= 0 && kind <= 3, "kind: 0 RAdam, 1 Adam, 2 SGD momentum + Nesterov, 3 SGD momentum");
+  hipLaunchKernelGGL(radam_schedule_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sched, (long long*)iterations, kind, beta1, beta2, decay,
+                     1.f);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

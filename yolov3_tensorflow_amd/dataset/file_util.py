@@ -147,24 +147,39 @@ class FileUtil(object):
         np.copyto(args[0], args[1])          # releases the GIL for the whole image
 
     @staticmethod
-    def host_batches(file_path, image_dir, image_size, batch_size, is_augment=True, is_test=False, seed=800, pool=None, pipe=None):
+    def host_batches(file_path, image_dir, image_size, batch_size, is_augment=True, is_test=False, seed=800, pool=None, pipe=None,
+                     rank=0, world=1):
         """the host half of get_dataset: (decoded images, padded transformed labels (N, T*5), augmentation draws or None, paths).
         ``pool``: a concurrent.futures executor that decodes the images of a batch in parallel (PIL releases the GIL while decoding);
         order, pairing and the random draws do not depend on it.  With ``pipe`` (a DeviceImagePipeline) the first element is a filled slot
-        of its staging ring instead of a list of arrays: the decode threads also copy the pixels into the pinned memory"""
+        of its staging ring instead of a list of arrays: the decode threads also copy the pixels into the pinned memory.
+
+        Data parallel (``world`` > 1): ``batch_size`` is the PER-RANK batch.  Every rank walks the same shuffled order with the same seed in
+        GLOBAL batches of ``batch_size * world`` images and takes the contiguous slice ``[rank * batch_size, (rank + 1) * batch_size)`` of
+        each -- the slice keras multi_gpu_model hands tower ``rank`` (reference trainer.py:40-43 splits one batch on axis 0).  The
+        augmentation draws of the whole global batch come from the one shared stream, so the concatenation of the ranks' batches is exactly
+        the batch (images, labels and draws) a single process with batch ``batch_size * world`` would train on."""
         names, labels = FileUtil._parse_label_file(file_path)
         if not names:
             raise ValueError('empty label file ' + file_path)
+        rank, world = int(rank), int(world)
+        if not 0 <= rank < world:
+            raise ValueError('rank %d outside world %d' % (rank, world))
         t_max = max(len(l) for l in labels)
         rng = np.random.RandomState(seed)
         order = np.arange(len(names))
+        gbatch = batch_size * world
+        lo = rank * batch_size
         while True:
             if not is_test:
                 rng.shuffle(order)                                   # shuffle-and-repeat (reference :79)
-            for i in range(0, len(order) - batch_size + 1 if not is_test else len(order), batch_size):
-                idx = order[i:i + batch_size]
-                if len(idx) < batch_size:                            # keras fit gets full batches; pad the last test batch by wrap-around
-                    idx = np.concatenate([idx, order[:batch_size - len(idx)]])
+            for i in range(0, len(order) - gbatch + 1 if not is_test else len(order), gbatch):
+                gidx = order[i:i + gbatch]
+                if len(gidx) < gbatch:                               # keras fit gets full batches; pad the last test batch by wrap-around
+                    gidx = np.concatenate([gidx, np.resize(order, gbatch - len(gidx))])
+                gdraws = [DatasetUtil.draw(rng) for _ in gidx] if (is_augment and not is_test) else None
+                idx = gidx[lo:lo + batch_size]
+                draws = gdraws[lo:lo + batch_size] if gdraws is not None else None
                 labs = -np.ones((batch_size, t_max, 5), dtype=np.float32)
                 paths = [os.path.join(image_dir, names[j]) for j in idx]
                 mapper = pool.map if pool is not None else map
@@ -176,22 +191,27 @@ class FileUtil(object):
                 for k, j in enumerate(idx):
                     lb = FileUtil.transform_label(labels[j], sizes[k], image_size)
                     labs[k, :len(lb)] = lb
-                draws = [DatasetUtil.draw(rng) for _ in idx] if (is_augment and not is_test) else None
                 yield imgs, labs.reshape(batch_size, t_max * 5), draws, paths
             if is_test:
                 return
 
     @staticmethod
     def get_dataset(file_path, image_dir, image_size, batch_size, is_augment=True, is_test=False, seed=800, device=None, num_workers=None,
-                    prefetch=3):
+                    prefetch=3, rank=None, world=None):
         """reference :62-114 (its tf.data pipeline decodes with AUTOTUNE parallelism and prefetches, :85-114).  Here ``num_workers`` threads
         (default: the CPUs of this process, at most 8 -- Python threads stop scaling there: ~3000 images/s of 500 x 375 JPEGs on the GPU box's host,
         tools/input_pipeline_bench.py) decode the JPEGs of a batch and a producer thread keeps ``prefetch`` decoded
-        batches ahead of the GPU; resize / normalise / augment then run in the GPU kernel on the consumer side."""
+        batches ahead of the GPU; resize / normalise / augment then run in the GPU kernel on the consumer side.
+        ``batch_size`` is the batch THIS process trains on.  ``rank`` / ``world`` (default: RANK / WORLD_SIZE of a torchrun launch; 0 / 1 for
+        a test set, which every rank reads whole) select this rank's slice of each global batch, see host_batches."""
         import concurrent.futures
         import queue
         import threading
         pipe = DeviceImagePipeline(batch_size, image_size, device=device, slots=max(1, prefetch) + 3)
+        if world is None:
+            world = 1 if is_test else int(os.environ.get('WORLD_SIZE', '1'))
+        if rank is None:
+            rank = 0 if is_test else int(os.environ.get('RANK', '0'))
         if num_workers is None:
             num_workers = max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
 
@@ -204,7 +224,7 @@ class FileUtil(object):
             def produce():
                 try:
                     for item in FileUtil.host_batches(file_path, image_dir, image_size, batch_size, is_augment, is_test, seed, pool=pool,
-                                                      pipe=pipe):
+                                                      pipe=pipe, rank=rank, world=world):
                         while not stop.is_set():
                             try:
                                 q.put(item, timeout=0.1)

@@ -92,7 +92,7 @@ class BNState(object):
     """one keras BatchNormalization: gamma/beta slots of the flat buffers + per-channel work vectors"""
 
     def __init__(self, g, name, C):
-        self.name, self.C = name, C
+        self.name, self.C, self.g = name, C, g
         ps = g.ps
         self.gamma = ps.add(Param(name + '/gamma', 'bn_gamma', (C,), (C,), BN_L2_GAMMA_DECAY), torch.ones(C))
         self.beta = ps.add(Param(name + '/beta', 'bn_beta', (C,), (C,), 0.0), torch.zeros(C))
@@ -114,7 +114,7 @@ class BNState(object):
     def fwd_finalize(self, psum, psq, P, row_stride, count, training):
         for bn, c0 in self.parts:
             if training:
-                ops.bn_finalize(psum[c0:], psq[c0:], P, row_stride, bn.C, count, bn.v_gamma, bn.v_beta, BN_EPSILON, BN_MOMENTUM,
+                ops.bn_finalize(psum[c0:], psq[c0:], P, row_stride, bn.C, count, bn.v_gamma, bn.v_beta, BN_EPSILON, bn.g.bn_momentum,
                                 bn.moving_mean, bn.moving_var, bn.scale, bn.shift, bn.mean, bn.rstd)
             else:           # keras learning_phase False (run.py:21-24): normalise with the moving statistics
                 ops.bn_eval_scale_shift(bn.v_gamma, bn.v_beta, bn.moving_mean, bn.moving_var, BN_EPSILON, bn.scale, bn.shift, bn.C)
@@ -149,7 +149,7 @@ class MultiBN(object):
             return BNState.fwd_finalize(self, psum, psq, P, row_stride, count, training)
         bns = [bn for bn, _ in self.parts]                                         # one launch for the (up to 4) groups
         ops.bn_finalize_grouped(psum, psq, P, row_stride, self.C, count, self._bounds(), [b.v_gamma for b in bns], [b.v_beta for b in bns],
-                                BN_EPSILON, BN_MOMENTUM, [b.moving_mean for b in bns], [b.moving_var for b in bns], self.scale, self.shift,
+                                BN_EPSILON, bns[0].g.bn_momentum, [b.moving_mean for b in bns], [b.moving_var for b in bns], self.scale, self.shift,
                                 self.mean, self.rstd)
 
     def bwd_finalize(self, partial, P, Cfull, which, count):
@@ -190,6 +190,7 @@ class Graph(object):
         self.bn_groups = []      # allocation units: a BNState or a MultiBN
         self.fwd, self.bwd = [], []
         self.training = True
+        self.bn_momentum = BN_MOMENTUM     # 1.0 while evaluating with batch statistics: the moving averages then stay as they are
         self._alloc = []
         self._repack_table = None
         self.wgrad_stream = None

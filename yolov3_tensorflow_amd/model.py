@@ -194,6 +194,27 @@ class YOLOv3Model(object):
         self.run_step()
         return float(self.loss_value.item())
 
+    def test_on_batch(self, images, labels):
+        """keras Model.test_on_batch as ``fit(validation_data=...)`` uses it (reference trainer.py:107-110): loss of one batch, nothing
+        updated.  The reference trains with the learning phase forced to 1 (run.py:21-22), so its validation pass also normalises with BATCH
+        statistics; the moving averages are only touched by the training function (momentum 1 here leaves them bit-identical).  What the
+        reference's loss graph does update even here is the rectified-loss image counter (yolov3_loss.py:151-152 sits inside the loss)."""
+        if self.loss_obj is None:
+            raise RuntimeError('compile(optimizer, loss) first')
+        g = self.g
+        self.stage_batch(images, labels)
+        with torch.cuda.device(self.device):
+            prev = (g.training, g.bn_momentum)
+            g.training, g.bn_momentum = True, 1.0
+            try:
+                g.run_forward()
+                self.loss_obj.launch(self)
+            finally:
+                g.training, g.bn_momentum = prev
+            ps = g.ps
+            l2 = (ps.flat.view(-1, engine.SLOT).double().pow(2).sum(dim=1) * ps.l2_table.double()).sum()
+            return float(self.loss_obj.total.double().item() + l2.item())
+
     def forward_only(self, images, training=False):
         """run the forward kernels (no capture); returns the three head tensors (device, float32, padded channels)"""
         g = self.g

@@ -327,6 +327,10 @@ def radam_schedule(sched, iterations, beta1, beta2, decay, warmup_coef):
     check(_lib.load().yolo_radam_schedule(_p(sched), _p(iterations), beta1, beta2, decay, warmup_coef, _stream()), 'yolo_radam_schedule')
 
 
+def optimizer_schedule(sched, iterations, kind, beta1, beta2, decay):
+    check(_lib.load().yolo_optimizer_schedule(_p(sched), _p(iterations), int(kind), beta1, beta2, decay, _stream()), 'yolo_optimizer_schedule')
+
+
 def radam_l2_blocks(n):
     r = _lib.load().yolo_radam_l2_blocks(n)
     if r < 0:

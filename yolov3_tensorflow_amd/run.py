@@ -20,8 +20,9 @@ np.random.seed(6)                                      # reference :27 (the weig
 def train(yolov3_trainer):
     """reference :31-38"""
     logging.info('loading training set: %s', FLAGS.train_label_path)
+    # FLAGS.batch_size is the global batch; under torchrun every rank reads its slice of it (FileUtil.host_batches)
     train_dataset = FileUtil.get_dataset(FLAGS.train_label_path, FLAGS.train_set_dir, image_size=FLAGS.input_image_size[0:2],
-                                         batch_size=FLAGS.batch_size, is_augment=FLAGS.is_augment, is_test=False)
+                                         batch_size=yolov3_trainer.batch_size, is_augment=FLAGS.is_augment, is_test=False)
     yolov3_trainer.train(train_dataset, None)
     logging.info('training finished')
 
@@ -50,7 +51,7 @@ def _detect(yolov3_trainer, yolov3_decoder, images):
 def test(yolov3_trainer, yolov3_decoder, save_path=None):
     """reference :41-80"""
     test_set = FileUtil.get_dataset(FLAGS.test_label_path, FLAGS.test_set_dir, image_size=FLAGS.input_image_size[0:2],
-                                    batch_size=FLAGS.batch_size, is_augment=False, is_test=True)
+                                    batch_size=yolov3_trainer.batch_size, is_augment=False, is_test=True)
     input_box_size = np.tile(FLAGS.input_image_size[1::-1], [2])          # [W, H, W, H]
     results = []
     for images, labels, image_paths in test_set:

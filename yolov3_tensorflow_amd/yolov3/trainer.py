@@ -24,10 +24,13 @@ class YOLOv3Trainer(object):
         self.head_channel_nums = FLAGS.head_channel_nums
         if FLAGS.gpu_mode == YOLOv3Trainer.CPU_MODE:
             raise RuntimeError("gpu_mode 'cpu' is not available: this is the MI355X-native path (no CPU fallback)")
-        self.model = YOLOv3Detector(self.backbone).build(self.input_image_size, self.head_channel_nums, FLAGS.head_names)
-        # reference :40-43 wraps the model with keras multi_gpu_model; here data parallelism is one process per GPU
-        # (torch.distributed / RCCL): see yolov3_tensorflow_amd.parallel.setup_data_parallel, called when WORLD_SIZE > 1.
+        # reference :40-43 wraps the model with keras multi_gpu_model, which splits the one batch across the towers; here data parallelism is
+        # one process per GPU (torch.distributed / RCCL, parallel.setup_data_parallel when WORLD_SIZE > 1) and FLAGS.batch_size stays the
+        # GLOBAL batch: each rank builds its static graph for batch_size / world images
         from yolov3_tensorflow_amd import parallel
+        self.batch_size = parallel.per_rank_batch(int(FLAGS.batch_size))
+        self.model = YOLOv3Detector(self.backbone).build(self.input_image_size, self.head_channel_nums, FLAGS.head_names,
+                                                         batch_size=self.batch_size)
         parallel.setup_data_parallel(self.model)
         self.model.summary()
         self.history = None
@@ -51,12 +54,17 @@ class YOLOv3Trainer(object):
             self.checkpoint_path = os.path.dirname(self.checkpoint_path)
         self.checkpoint_path = os.path.join(self.checkpoint_path, FLAGS.checkpoint_name)
 
-        # optimizer (reference :69-75); RAdam(lr=1e-3) ignores FLAGS.init_lr exactly like the reference
+        # optimizer (reference :69-75): SGD-Nesterov unless 'adam' / 'radam'; RAdam(lr=1e-3) ignores FLAGS.init_lr exactly like the reference
+        # (every epoch the LearningRateScheduler overwrites the rate anyway, :94)
         if FLAGS.optimizer == 'radam':
             from yolov3_tensorflow_amd.utils.radam import RAdam
             optimizer = RAdam(lr=1e-3)
+        elif FLAGS.optimizer == 'adam':
+            from yolov3_tensorflow_amd.utils.optimizers import Adam
+            optimizer = Adam(lr=FLAGS.init_lr, amsgrad=True)
         else:
-            raise NotImplementedError("optimizer '%s': only 'radam' is on the MI355X hot path (SURVEY.md section 8a O1)" % FLAGS.optimizer)
+            from yolov3_tensorflow_amd.utils.optimizers import SGD
+            optimizer = SGD(lr=FLAGS.init_lr, momentum=0.95, nesterov=True)
         self.loss_object = YOLOv3Loss(FLAGS.head_grid_sizes, FLAGS.class_num, FLAGS.anchor_boxes, FLAGS.iou_thresh,
                                       FLAGS.loss_weights, rectified_coord_num=FLAGS.rectified_coord_num,
                                       rectified_loss_weight=FLAGS.rectified_loss_weight, is_focal_loss=FLAGS.is_focal_loss,
@@ -85,8 +93,10 @@ class YOLOv3Trainer(object):
 
     def train(self, train_set, val_set, train_steps=FLAGS.steps_per_epoch, val_steps=FLAGS.validation_steps):
         """reference :99-115.  ``train_set`` yields (images float32 (N,H,W,3) in [0,1] BGR, labels float32 (N, T*5) padded -1)."""
+        from yolov3_tensorflow_amd import parallel
         it = iter(train_set)
-        best, wait = np.inf, 0
+        stopper = parallel.EarlyStopping(self.stop_min_delta, self.stop_patience)
+        val_it = iter(val_set) if val_set is not None else None
         history = {'loss': [], 'lr': []}
         is_main = self.model.rank == 0
         callbacks = [self.tensorboard, self.log_callback] if is_main else []
@@ -102,25 +112,35 @@ class YOLOv3Trainer(object):
             for _ in range(train_steps):
                 images, labels = next(it)
                 losses.append(self.model.train_on_batch(images, labels))
-            epoch_loss = float(np.mean(losses))                              # keras reports the running mean over the epoch
-            self.model.check_device_protocols()
+            # keras reports the running mean over the epoch; data parallel: the mean over the ranks' shards, the same number everywhere
+            epoch_loss = parallel.agree_mean(float(np.mean(losses)), self.model.device, self.model.process_group)
+            failure = None
+            try:
+                self.model.check_device_protocols()
+            except (RuntimeError, FloatingPointError) as e:
+                failure = e
+            if parallel.agree_any(failure is not None, self.model.device, self.model.process_group):      # all ranks leave together
+                raise failure if failure is not None else RuntimeError('another rank reported a device-protocol failure')
             history['loss'].append(epoch_loss)
             history['lr'].append(lr)
+            # the per-head terms as the callbacks see them at the epoch's end (the last step's values, reference yolov3_loss.py:115-134):
+            # rows xy, wh, noobj, obj, class, rectified; columns head /8, /16, /32
+            history.setdefault('terms', []).append(self.loss_object.terms.detach().cpu().numpy().copy())
+            logs = {'loss': epoch_loss, 'lr': lr}
+            if val_it is not None:                                           # fit(validation_data=val_set, validation_steps=val_steps) (reference :107-110)
+                val = [self.model.test_on_batch(*next(val_it)[:2]) for _ in range(val_steps)]
+                logs['val_loss'] = parallel.agree_mean(float(np.mean(val)), self.model.device, self.model.process_group)
+                history.setdefault('val_loss', []).append(logs['val_loss'])
             if is_main:
-                logs = {'loss': epoch_loss, 'lr': lr}
-                self.tensorboard.on_epoch_end(epoch, {'loss': epoch_loss})   # MyTensorBoard (reference :96)
+                self.tensorboard.on_epoch_end(epoch, {k: v for k, v in logs.items() if k != 'lr'})   # MyTensorBoard (reference :96)
                 self.log_callback.on_epoch_end(epoch, logs)                  # DetailLossLogger (reference :95)
                 if (epoch + 1) % self.ckpt_period == 0:                      # ModelCheckpoint(period) (reference :90-91)
                     path = self.checkpoint_path.format(epoch=epoch + 1, loss=epoch_loss)
                     self.model.save_weights(path, full_state=bool(FLAGS.get('full_state_resume')), epoch=epoch)
                     logging.info('saved %s', path)
-            if best - epoch_loss > self.stop_min_delta:                      # EarlyStopping(monitor='loss') (reference :92-93)
-                best, wait = epoch_loss, 0
-            else:
-                wait += 1
-                if wait >= self.stop_patience:
-                    logging.info('early stopping at epoch %d', epoch + 1)
-                    break
+            if stopper.should_stop(epoch_loss):                              # EarlyStopping(monitor='loss') (reference :92-93)
+                logging.info('early stopping at epoch %d', epoch + 1)
+                break
         if is_main:
             self.tensorboard.on_train_end()
         self.history = history

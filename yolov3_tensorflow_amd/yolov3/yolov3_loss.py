@@ -75,6 +75,10 @@ class YOLOv3Loss(object):
 
     def launch(self, model):
         """enqueue loss forward+backward for the model's current head logits; d(logits) lands in the heads' dy buffers"""
+        scale = backend.loss_scale()
+        if self.cfg.grad_scale16 != scale:           # backend.set_loss_scale() after compile: the optimizer divides by the CURRENT scale
+            self.cfg.grad_scale16 = scale            # (radam.launch reads it per step), so the 16-bit d(logits) must carry the same one
+            model._graphs = None                     # a captured hipGraph holds the old kernel argument
         ops.loss_fwd_bwd(self.cfg, self.N, self.N * model.world_size, [h.buf for h in model.heads], self.labels, self.current_num,
                          self.terms, self.total, self.ws, dlogits_bf16=[h.dy for h in model.heads], assign_out=self.assign)
 
