@@ -110,3 +110,24 @@ def test_get_dataset_yields_device_batches(tmp_path):
         np.testing.assert_array_equal(x[n].cpu().numpy(), ods.to_float_bgr(ods.letterbox(raw, (64, 64))))
         k = 1 + int(paths[n].split('/')[-1][0]) % 3
         assert (y[n].reshape(-1, 5)[:k, 4] == np.arange(k)).all() and (y[n].reshape(-1, 5)[k:] == -1).all()
+
+
+def test_augment_image_entry_point():
+    """DatasetUtil.augment_image (reference dataset_util.py:105-115: map _augment over a stream of images): the same draws through the
+    oracle's augment give the same pixels; the channel order of the input is kept; non-8-bit inputs are refused"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from oracle import dataset as ods
+    from yolov3_tensorflow_amd.dataset.dataset_util import DatasetUtil
+    rng = np.random.RandomState(5)
+    imgs = [(rng.randint(0, 256, size=(48, 64, 3)).astype(np.float32) * np.float32(1.0 / 255)) for _ in range(3)]
+    got = [t.cpu().numpy() for t in DatasetUtil.augment_image(iter(imgs), seed=77)]
+    draw_rng = np.random.RandomState(77)
+    for x, y in zip(imgs, got):
+        d = DatasetUtil.draw(draw_rng)
+        want = ods.augment(x, d['noise'], d['color_order'], d['brightness_delta'], d['saturation_factor'], d['contrast_factor'],
+                           (d['seed0'], d['seed1']), 0)
+        assert y.shape == x.shape and y.min() >= 0.0 and y.max() <= 1.0
+        np.testing.assert_allclose(y, want, rtol=0, atol=3e-6)
+    with pytest.raises(ValueError):
+        list(DatasetUtil.augment_image([np.full((8, 8, 3), 0.3337, np.float32)]))

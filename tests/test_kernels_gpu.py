@@ -586,6 +586,47 @@ def test_mixconv_fwd_dgrad_wgrad(dev, f, N, H, W):
         torch.testing.assert_close(a.cpu(), 2 * b.grad, rtol=1e-3, atol=2e-3 * max(1.0, b.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize('C,k', [(64, 3), (128, 5), (32, 9)])
+def test_lone_depthwise_conv_bn_graph(dev, C, k):
+    """BasicBackbone.depthwise_conv_bn (reference basic_backbone.py:45-66,140-150) as a graph node: forward of DepthwiseConv2D(k) -> BN -> ReLU
+    and the weight gradient through the engine, against F.conv2d(groups=C) + batch_norm + autograd in float32 on the same bf16 operands"""
+    from yolov3_tensorflow_amd import engine, ops
+    from yolov3_tensorflow_amd.backbone.basic_backbone import BasicBackbone
+    N, H, W = 2, 12, 10
+    g = engine.Graph(N, dev)
+    x = g.input(H, W, 3)
+    c = BasicBackbone.conv_bn(x, C, kernel_size=(1, 1))
+    a = BasicBackbone.activation(c)
+    out = BasicBackbone.activation(BasicBackbone.depthwise_conv_bn(a, kernel_size=(k, k)))
+    g.finalize([])
+    names = list(g.ps.params.keys())
+    assert 'depthwise_conv2d/depthwise_kernel' in names and g.ps.params['depthwise_conv2d/depthwise_kernel'].tf_shape == (k, k, C, 1)
+    gen = torch.Generator().manual_seed(4)
+    g.images.copy_(torch.rand(N, H, W, 3, generator=gen))
+    g.run_forward()
+    torch.cuda.synchronize()
+    dwop = [op for op in g.tape if isinstance(op, engine.MixConvOp)][0]
+    xin = dwop.y.x.buf.float().cpu().requires_grad_(True)
+    wdev = g.ps.view(g.ps.params['depthwise_conv2d/depthwise_kernel'], g.ps.bf16).float().cpu().reshape(k, k, C).requires_grad_(True)
+    yref = F.conv2d(xin.permute(0, 3, 1, 2), wdev.permute(2, 0, 1).unsqueeze(1), padding=k // 2, groups=C).permute(0, 2, 3, 1)
+    torch.testing.assert_close(dwop.y.buf.float().cpu(), yref.detach(), rtol=1e-2, atol=1e-2)
+    yq = dwop.y.buf.float().cpu()
+    mean, var = yq.mean((0, 1, 2)), yq.var((0, 1, 2), unbiased=False)
+    zref = torch.relu((yq - mean) / torch.sqrt(var + 1e-5))
+    torch.testing.assert_close(out.buf.float().cpu(), zref, rtol=2e-2, atol=2e-2)
+    out.grad.copy_(torch.randn(out.shape, generator=gen).to(ACT()))
+    go = out.grad.float().cpu()
+    for f in g.bwd[:2]:                                      # the two ops on top: BN+ReLU apply backward, depthwise backward
+        f()
+    g.flush_wgrad()
+    torch.cuda.synchronize()
+    yref.backward(dwop.y.dy.float().cpu())
+    dw = g.ps.view(g.ps.params['depthwise_conv2d/depthwise_kernel'], g.ps.grad).cpu().reshape(k, k, C)
+    torch.testing.assert_close(dw, wdev.grad, rtol=1e-3, atol=1e-3 * max(1.0, wdev.grad.abs().max().item()))
+    torch.testing.assert_close(dwop.y.x.grad.float().cpu(), xin.grad, rtol=1e-2, atol=2e-2)
+    assert go.abs().sum() > 0
+
+
 def test_pack_input(dev):
     from yolov3_tensorflow_amd import ops
     img = torch.rand(2, 6, 5, 3)

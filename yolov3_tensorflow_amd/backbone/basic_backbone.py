@@ -31,8 +31,18 @@ class BasicBackbone(object):
 
     @classmethod
     def depthwise_conv(cls, input_x, **conv_params):
-        """reference :45-66 -- only reachable through MixNet18's mixed depthwise block here"""
-        raise NotImplementedError('use MixNet18 (mixed depthwise block); a lone DepthwiseConv2D is not on the hot path')
+        """reference :45-66 -- defaults 3x3, stride 1, 'same', no bias, he_normal, L2 5e-4.  Runs as a one-group launch of the mixed
+        depthwise kernel (MixNet18's block uses the four-group form, engine.Graph.mix_depthwise_conv_bn)"""
+        conv_params.setdefault('kernel_size', (3, 3))
+        conv_params.setdefault('strides', (1, 1))
+        conv_params.setdefault('padding', 'same')
+        conv_params.setdefault('use_bias', False)
+        unknown = set(conv_params) - {'kernel_size', 'strides', 'padding', 'use_bias', 'depthwise_initializer', 'depthwise_regularizer'}
+        if unknown:
+            raise TypeError('unsupported DepthwiseConv2D arguments: %s' % sorted(unknown))
+        if tuple(conv_params['strides']) != (1, 1) or conv_params['padding'] != 'same' or conv_params['use_bias']:
+            raise NotImplementedError("DepthwiseConv2D on this path: stride 1, 'same', no bias (every reference call site, mixnet18.py:43)")
+        return input_x.g.depthwise_conv(input_x, kernel_size=conv_params['kernel_size'])
 
     @classmethod
     def batch_normalization(cls, input_x):

@@ -326,6 +326,26 @@ class Graph(object):
         self.tape.append(MixConvOp(self, y))
         return Val(self, 'bn', y.shape, src=y, bn=mbn)
 
+    def depthwise_conv(self, x, kernel_size=(3, 3)):
+        """a lone keras DepthwiseConv2D (depth multiplier 1, stride 1, 'same', no bias, he_normal, L2 5e-4: reference basic_backbone.py:45-66) =
+        the mixed depthwise launch with one channel group.  The kernel wants C / 8 to be a power of two <= 64."""
+        x = self.materialize(x, relu=False)
+        N, H, W, C = x.shape
+        k = int(kernel_size[0])
+        if k not in (1, 3, 5, 7, 9) or int(kernel_size[1]) != k:
+            raise NotImplementedError('DepthwiseConv2D kernel sizes on this path: 1, 3, 5, 7, 9 (square)')
+        if C % 8 or (C // 8) & (C // 8 - 1) or C > 512:
+            raise NotImplementedError('DepthwiseConv2D over %d channels: C / 8 must be a power of two <= 64' % C)
+        name = self.ps.layer_name('depthwise_conv2d')
+        wp = Param(name + '/depthwise_kernel', 'dw_kernel', (k, k, C, 1), (k, k, C), L2_CONV_DECAY)
+        self.ps.add(wp, self.ps.he_normal((k, k, C, 1), k * k * C).reshape(k, k, C))
+        y = Val(self, 'conv', (N, H, W, C), x=x, wps=[wp], mp=ops.mix_problem(N, H, W, C, [0, C, C, C, C], [k, 3, 3, 3]), f32=False)
+        y.cell = self._buffer(y.shape)
+        y.dy_cell = self._buffer(y.shape)
+        y.wants_stats = False
+        self.tape.append(MixConvOp(self, y))
+        return y
+
     @staticmethod
     def dw_to_dev(w, wp):
         return w.reshape(wp.dev_shape)
@@ -630,8 +650,9 @@ class MixConvOp(object):
         y.buf = y.cell['t']
         y.dy = y.dy_cell['t']
         ps = g.ps
-        self.w = [ps.view(wp, ps.bf16) for wp in y.wps]
-        self.dw = [ps.view(wp, ps.grad) for wp in y.wps]
+        pad = [None] * (4 - len(y.wps))                      # a lone DepthwiseConv2D has one (non-empty) channel group
+        self.w = [ps.view(wp, ps.bf16) for wp in y.wps] + pad
+        self.dw = [ps.view(wp, ps.grad) for wp in y.wps] + pad
         C = y.shape[3]
         self.P = ops.reduce_rows(y.M, C)
         self.part = torch.zeros(self.P, 2, C, device=g.dev)
