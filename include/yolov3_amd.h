@@ -82,6 +82,15 @@ int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, const void* 
 size_t yolo_conv2d_wgrad_workspace_bytes(const yolo_conv_problem* p);
 int yolo_conv2d_wgrad_reduce(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
                              void* workspace, size_t workspace_bytes, int accumulate, void* stream);
+/* The training step's form: the slab pass alone into a PRIVATE region of a slab arena (yolo_conv2d_wgrad_splits(p) slabs of
+ * Cout*R*S*Cin floats; with one split the kernel stores straight into dw and `slabs` is not touched), and ONE summing launch per gradient
+ * bucket for all its layers once the bucket's backward pass is complete (the gradient exchange / optimizer of the bucket follow it).
+ * table_dev: device int64 [nentries][5] = {first float4 of the layer's dw in `grads`, first float4 of its slabs in `arena`, float4s per
+ * slab, number of slabs, first workgroup}; total_blocks = sum of ceil(float4s / 64).  Same summation order as yolo_conv2d_wgrad_reduce. */
+int yolo_conv2d_wgrad_splits(const yolo_conv_problem* p);
+int yolo_conv2d_wgrad_slabs(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw, float* slabs,
+                            size_t slab_bytes, void* stream);
+int yolo_wgrad_reduce_batched(const int64_t* table_dev, int nentries, int total_blocks, const float* arena, float* grads, void* stream);
 /* bf16 [Cout][R][S][Cin] -> bf16 [Cin][R][S][Cout] with flipped taps (operand layout of yolo_conv2d_dgrad). */
 int yolo_repack_dgrad_weights(const void* w_fwd, void* w_dgrad, int Cout, int R, int S, int Cin, void* stream);
 /* the same for every layer in ONE launch.  table_dev: device int32 [nlayers][8] = {src element offset into w_fwd_flat, dst element

@@ -145,3 +145,18 @@ def test_weight_layout_roundtrip_and_checkpoint(mocked_kernels, tmp_path):
     np.testing.assert_array_equal(m.get_weights()['conv2d_5/kernel'], w2['conv2d_5/kernel'])
     with pytest.raises(KeyError):
         m.set_weights({'conv2d/kernel': w['conv2d/kernel']})
+
+
+def test_screenshot_is_below_the_xy_loss_floor():
+    """the reference's only numbers for the training path (images/tensorboard_loss.jpg: epoch loss 16.2, xy terms 1.25 + 0.0064 + 0.0227 for one
+    batch) are unreachable under its current loss code and defaults: the xy cross-entropy (yolov3_loss.py:350-356) is bounded below by the
+    entropy of the fractional target, which on the 20 sample labels amounts to 24.4 per image (6.2 for the best 3-image batch)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import reference_default_run as rdr
+    floor = rdr.xy_loss_floor()
+    assert floor.shape == (20,) and (floor > 0).all()
+    shot = rdr.SCREENSHOT
+    xy_shot = sum(shot[h]['xy'] for h in ('head_8', 'head_16', 'head_32'))
+    assert np.sort(floor)[:3].mean() > 4 * xy_shot             # no 3-image batch can show the screenshot's xy terms
+    assert floor.mean() > shot['loss']                         # the xy terms alone exceed the screenshot's whole epoch loss
+    assert floor.mean() == pytest.approx(24.38, abs=0.05)

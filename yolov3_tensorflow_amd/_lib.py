@@ -56,6 +56,9 @@ SIGNATURES = {
     'yolo_conv2d_wgrad': (I, [CP, P, P, P, P, I, P]),
     'yolo_conv2d_wgrad_workspace_bytes': (C.c_size_t, [CP]),
     'yolo_conv2d_wgrad_reduce': (I, [CP, P, P, P, P, P, C.c_size_t, I, P]),
+    'yolo_conv2d_wgrad_splits': (I, [CP]),
+    'yolo_conv2d_wgrad_slabs': (I, [CP, P, P, P, P, P, C.c_size_t, P]),
+    'yolo_wgrad_reduce_batched': (I, [P, I, I, P, P, P]),
     'yolo_repack_dgrad_weights': (I, [P, P, I, I, I, I, P]),
     'yolo_repack_dgrad_weights_batched': (I, [P, P, P, I, I, P]),
     'yolo_reduce_rows': (I, [I, I]),

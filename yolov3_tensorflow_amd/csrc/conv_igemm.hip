@@ -1078,6 +1078,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restr
   }
 }
 
+// The same summation for MANY layers in one launch (a whole gradient bucket): every layer keeps its slabs in a private region of one
+// arena until its bucket is complete, then one grid sums them all -- 31 small launches per step (each 4-70 us, mostly ramp and tail)
+// become 3.  tab[e] = {first float4 of dW in `grads`, first float4 of the slabs in `arena`, float4s per slab, slabs, first workgroup}.
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const long long* __restrict__ tab, int n, const float4* __restrict__ arena,
+                                                                   float4* __restrict__ grads) {
+  __shared__ float4 red[4][64];
+  int e = 0;
+  for (int k = 1; k < n; ++k) e = ((long long)blockIdx.x >= tab[k * 5 + 4]) ? k : e;      // n <= a few dozen, uniform: scalar loads
+  const long long dst4 = tab[e * 5], src4 = tab[e * 5 + 1], n4 = tab[e * 5 + 2];
+  const int nslab = (int)tab[e * 5 + 3];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long long i = ((long long)blockIdx.x - tab[e * 5 + 4]) * 64 + col;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float4* p = arena + src4 + i;
+    int z = grp;
+    for (; z + 12 < nslab; z += 16) {
+      const float4 a = p[(size_t)z * n4], b = p[(size_t)(z + 4) * n4], c = p[(size_t)(z + 8) * n4], d = p[(size_t)(z + 12) * n4];
+      s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+      s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; z < nslab; z += 4) {
+      const float4 a = p[(size_t)z * n4];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+  }
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && i < n4) {
+    float4 r = red[0][col];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { r.x += red[k][col].x; r.y += red[k][col].y; r.z += red[k][col].z; r.w += red[k][col].w; }
+    grads[dst4 + i] = r;
+  }
+}
+
 // [Cout][RS][Cin] -> [Cin][RS flipped][Cout], 32x32 tiles through LDS.
 __global__ void repack_dgrad_kernel(const bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int Cout, int RS, int Cin) {
   __shared__ bf16_t tile[32][33];
@@ -1521,6 +1557,41 @@ extern "C" int yolo_conv2d_wgrad_reduce(const yolo_conv_problem* p, const void* 
   const int n4 = (int)(n / 4);                         // Cin % 8 == 0
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n4 + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float4*)workspace, pl.split_k,
                      (long long)(n / 4), (float4*)dw, n4, accumulate);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_conv2d_wgrad_splits(const yolo_conv_problem* p) {
+  WgradPlan pl;
+  static const char dummy = 0;
+  if (!p || plan_wgrad(p, &dummy, &dummy, 0, g_wgrad_target, &pl)) return YOLO_ERR_INVALID_ARG;
+  return pl.split_k;
+}
+
+extern "C" int yolo_conv2d_wgrad_slabs(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw, float* slabs,
+                                       size_t slab_bytes, void* stream) {
+  YOLO_CHECK_ARG(p && src1 && dy && dw, "null pointer");
+  WgradPlan pl;
+  int rc = plan_wgrad(p, src0, src1, 0, g_wgrad_target, &pl);
+  if (rc) return rc;
+  const size_t n = (size_t)p->Cout * (size_t)pl.g.Kg;
+  if (pl.split_k == 1) {                              // one workgroup per tile: plain stores straight into dw, nothing to sum
+    launch_wgrad(p, pl, dy, dw, (long long)n, (hipStream_t)stream);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+  }
+  YOLO_CHECK_ARG(slabs && slab_bytes >= (size_t)pl.split_k * n * sizeof(float), "slab region too small (yolo_conv2d_wgrad_workspace_bytes)");
+  YOLO_CHECK_ARG((reinterpret_cast<uintptr_t>(slabs) & 15) == 0, "slabs must be 16-byte aligned");
+  launch_wgrad(p, pl, dy, slabs, (long long)n, (hipStream_t)stream);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_wgrad_reduce_batched(const int64_t* table_dev, int nentries, int total_blocks, const float* arena, float* grads, void* stream) {
+  YOLO_CHECK_ARG(table_dev && arena && grads && nentries > 0 && total_blocks > 0, "bad argument");
+  YOLO_CHECK_ARG((reinterpret_cast<uintptr_t>(arena) & 15) == 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0, "arena / grads must be 16-byte aligned");
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table_dev, nentries,
+                     (const float4*)arena, (float4*)grads);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

@@ -76,6 +76,24 @@ def conv2d_wgrad_reduce(p, src1, dy, dw, workspace, src0=None, accumulate=False)
           'yolo_conv2d_wgrad_reduce')
 
 
+def conv2d_wgrad_splits(p):
+    r = _lib.load().yolo_conv2d_wgrad_splits(C.byref(p))
+    if r < 1:
+        raise _lib.YoloNativeError('yolo_conv2d_wgrad_splits rejected the problem')
+    return r
+
+
+def conv2d_wgrad_slabs(p, src1, dy, dw, slabs, src0=None):
+    """the slab pass of the two-phase weight gradient into this layer's private slab region (summed later, per bucket, by
+    wgrad_reduce_batched); with a single split the kernel writes dw directly and ``slabs`` may be None"""
+    check(_lib.load().yolo_conv2d_wgrad_slabs(C.byref(p), _p(src0), _p(src1), _p(dy), _p(dw), _p(slabs),
+                                              0 if slabs is None else slabs.numel() * slabs.element_size(), _stream()), 'yolo_conv2d_wgrad_slabs')
+
+
+def wgrad_reduce_batched(table_dev, nentries, total_blocks, arena, grads):
+    check(_lib.load().yolo_wgrad_reduce_batched(_p(table_dev), nentries, total_blocks, _p(arena), _p(grads), _stream()), 'yolo_wgrad_reduce_batched')
+
+
 def repack_dgrad_weights(w_fwd, w_dgrad, Cout, R, S, Cin):
     check(_lib.load().yolo_repack_dgrad_weights(_p(w_fwd), _p(w_dgrad), Cout, R, S, Cin, _stream()), 'yolo_repack_dgrad_weights')
 
