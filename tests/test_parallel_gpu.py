@@ -1,6 +1,6 @@
 """Two data-parallel ranks on ONE MI355X (both processes use cuda:0, gloo carries the all-reduce through the host): the real step path
-of world_size > 1 -- bucketed gradient all-reduce on the communication stream, overlapped with the rest of the backward pass, the
-1/world scaling in the optimizer, the three-kernel BatchNorm backward -- rehearsed on hardware.  RCCL itself needs one GPU per rank and is
+of world_size > 1 -- bucketed gradient all-reduce on the communication stream followed by that bucket's RAdam + L2 launch, both overlapped
+with the rest of the backward pass, the 1/world scaling in the optimizer, the three-kernel BatchNorm backward -- rehearsed on hardware.  RCCL itself needs one GPU per rank and is
 exercised by the driver's multi-GPU bench; everything around the collective is the same code.
 
 Checked: both ranks hold bit-identical weights after 3 steps (same summed gradient, same update), those weights differ from the start,
@@ -43,17 +43,21 @@ if model.loss_obj.current_num is not None:
 g_sum = g_local.clone()
 dist.all_reduce(g_sum, op=dist.ReduceOp.SUM)
 # step 1 through the real path, gradient captured just before the optimizer consumes it
-captured = {}
-orig_update = model._update
-def spy():
+# (per gradient bucket: each range is all-reduced and then updated on the communication stream while the backward pass continues)
+captured = torch.zeros_like(g_sum)
+ranges = []
+orig_range = opt.launch_range
+def spy(m, lo, hi, first):
     torch.cuda.synchronize()
-    captured['g'] = model.g.ps.grad.clone()
-    orig_update()
-model._update = spy
+    captured[lo:hi] = model.g.ps.grad[lo:hi]
+    ranges.append((lo, hi, first))
+    orig_range(m, lo, hi, first)
+opt.launch_range = spy
 model.run_step()
-model._update = orig_update
+opt.launch_range = orig_range
 torch.cuda.synchronize()
-err = float((captured['g'] - g_sum).abs().max()) / max(float(g_sum.abs().max()), 1e-12)
+assert len(ranges) == 3 and [r[2] for r in ranges] == [True, False, False] and sum(hi - lo for lo, hi, _ in ranges) == model.g.ps.n, ranges
+err = float((captured - g_sum).abs().max()) / max(float(g_sum.abs().max()), 1e-12)
 for _ in range(2):
     model.run_step()
 torch.cuda.synchronize()

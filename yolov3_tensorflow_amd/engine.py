@@ -400,9 +400,18 @@ class Graph(object):
                 op.dg_off = n_dg
                 n_dg += _round_up(op.y.wp.numel, SLOT)
         self.w_dgrad = torch.zeros(max(n_dg, SLOT), dtype=backend.torch_dtype(), device=dev)
-        # one slab workspace for the two-phase weight gradients (they run back to back on one stream)
-        ws_bytes = max([ops.conv2d_wgrad_workspace_bytes(op.y.p) for op in self.tape if isinstance(op, ConvOp)] +
-                       [ops.dwconv_mix_wgrad_workspace_bytes(op.y.mp) for op in self.tape if isinstance(op, MixConvOp)] + [16])
+        # slab arena of the two-phase weight gradients: every convolution whose plan splits the pixels keeps its partial [Cout][R][S][Cin]
+        # slabs in a PRIVATE region until its gradient bucket is complete; one launch per bucket then sums all of them (bucket_done).
+        # (the depthwise weight gradients keep their own shared workspace: they run back to back on one stream and sum right away)
+        n_slab = 0
+        for op in self.tape:
+            if isinstance(op, ConvOp):
+                op.splits = ops.conv2d_wgrad_splits(op.y.p)
+                op.slab_off = n_slab
+                if op.splits > 1:
+                    n_slab += op.splits * op.y.wp.numel
+        self.slab_arena = torch.empty(max(n_slab, 4), dtype=torch.float32, device=dev)
+        ws_bytes = max([ops.dwconv_mix_wgrad_workspace_bytes(op.y.mp) for op in self.tape if isinstance(op, MixConvOp)] + [16])
         self.wgrad_ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
         # workspace + hand-off words of the single-launch BatchNorm backward (all on the main stream, one at a time)
         cmax = max([op.out.shape[3] for op in self.tape if isinstance(op, ApplyOp)] + [8])
@@ -438,6 +447,19 @@ class Graph(object):
         self.bucket_tail = hi                                  # [0, bucket_tail) remains after the backward pass (None: everything)
         if self.buckets:
             self.bucket_cut, self.bucket_offset = self.buckets[0][0], self.buckets[0][1]     # (kept: first bucket, for introspection / tests)
+        # slab-summing tables, one per bucket range (and one for everything): rows {dw float4 offset, slab float4 offset, float4s per slab,
+        # slabs, first workgroup} of the bucket's split convolutions
+        n = self.ps.n
+        self.bucket_ranges = [(lo, n if hi_ is None else hi_) for _, lo, hi_ in self.buckets] + [(0, n if self.bucket_tail is None else self.bucket_tail)]
+        self.reduce_tables = {}
+        for lo, hi_ in self.bucket_ranges + [(0, n)]:
+            rows, blocks = [], 0
+            for op in self.tape:
+                if isinstance(op, ConvOp) and op.splits > 1 and lo <= op.y.wp.offset < hi_:
+                    n4 = op.y.wp.numel // 4
+                    rows.append([op.y.wp.offset // 4, op.slab_off // 4, n4, op.splits, blocks])
+                    blocks += (n4 + 63) // 64
+            self.reduce_tables[(lo, hi_)] = (torch.tensor(rows, dtype=torch.int64, device=dev) if rows else None, len(rows), blocks)
 
     def refresh_dgrad_weights(self):
         """flipped/transposed bf16 weight copies for the data-gradient pass, all layers in one launch"""
@@ -466,16 +488,27 @@ class Graph(object):
         if self._repack_event is not None:        # the data-gradient weight copies were refreshed on the side stream (refresh_dgrad_async)
             torch.cuda.current_stream(self.dev).wait_event(self._repack_event)
             self._repack_event = None
-        cuts = {cut: (lo, hi) for cut, lo, hi in self.buckets} if self.on_bucket is not None else {}
+        cuts = {cut: (lo, self.ps.n if hi is None else hi) for cut, lo, hi in self.buckets}
         for i, f in enumerate(self.bwd):
             f()
             if i in cuts:
-                self.flush_wgrad()
-                lo, hi = cuts[i]
-                self.on_bucket(lo, self.ps.n if hi is None else hi)   # every gradient of this bucket has been enqueued (main + wgrad stream)
-        self.flush_wgrad()
+                self.bucket_done(*cuts[i])
+        self.bucket_done(*self.bucket_ranges[-1])
         if side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(side)
+
+    def reduce_slabs(self, lo, hi):
+        tab, n, blocks = self.reduce_tables[(lo, hi)]
+        if n:
+            ops.wgrad_reduce_batched(tab, n, blocks, self.slab_arena, self.ps.grad)
+
+    def bucket_done(self, lo, hi):
+        """every gradient of the parameter range [lo, hi) has been enqueued (main stream: BatchNorm gradients; weight-gradient stream: the
+        slab passes).  Hand what is pending to the weight-gradient stream together with the ONE launch that sums the bucket's slabs, then
+        tell the owner (gradient exchange and / or the optimizer launch of this bucket, both behind that launch on the side stream)"""
+        self.on_wgrad_stream(lambda: self.reduce_slabs(lo, hi), flush=True)
+        if self.on_bucket is not None:
+            self.on_bucket(lo, hi)
 
     def owned_tensors(self):
         """every device tensor this graph (its parameter store, ops and BatchNorm states) holds"""
@@ -582,6 +615,7 @@ class ConvOp(object):
             self.src0, self.src1 = None, x
         if self.needs_dgrad():
             self.w_dg = g.w_dgrad[self.dg_off:self.dg_off + y.wp.numel]
+        self.slabs = g.slab_arena[self.slab_off:self.slab_off + self.splits * y.wp.numel] if self.splits > 1 else None
         if y.bp is not None:
             C = y.shape[3]
             self.brow = ops.reduce_rows(y.M, C)
@@ -617,7 +651,7 @@ class ConvOp(object):
     def _wgrad(self):
         y = self.y
         s0 = None if self.src0 is None else self.src0.buf
-        ops.conv2d_wgrad_reduce(y.p, self.src1.buf, y.dy, self.dw, self.g.wgrad_ws, src0=s0)
+        ops.conv2d_wgrad_slabs(y.p, self.src1.buf, y.dy, self.dw, self.slabs, src0=s0)
         if self.dbias is not None:
             C = y.shape[3]
             ops.bn_stats(y.dy, y.M, C, self.bpart)

@@ -47,8 +47,10 @@ class YOLOv3Model(object):
         self.use_hip_graph = False
         self.overlap_wgrad = True          # weight-gradient GEMMs on a second stream (see engine.Graph.run_backward)
         self.overlap_allreduce = True      # data parallel: each stage's gradient bucket is all-reduced while the earlier layers still run backward
+        self.bucket_updates = True         # eager mode: RAdam + L2 per gradient bucket, overlapped with the rest of the backward pass
         self._comm_stream = None
         self._pending = []
+        self._step_ranges = []
         self.loss_value = torch.zeros(1, device=self.device)
         self.l2_value = torch.zeros(1, device=self.device)
 
@@ -84,9 +86,10 @@ class YOLOv3Model(object):
         if self.overlap_wgrad and g.wgrad_stream is None:
             g.wgrad_stream = torch.cuda.Stream(device=self.device)
             g.use_side_stream(g.wgrad_stream)
-            for t in (getattr(self.loss_obj, '__dict__', {}) or {}).values():
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    t.record_stream(g.wgrad_stream)
+            for owner in (self.loss_obj, self.optimizer, self):      # the per-bucket optimizer launches run on this stream too
+                for t in (getattr(owner, '__dict__', {}) or {}).values():
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(g.wgrad_stream)
         elif not self.overlap_wgrad:
             g.wgrad_stream = None
         g.run_forward()
@@ -126,19 +129,43 @@ class YOLOv3Model(object):
         g.images.copy_(img.to(torch.float32), non_blocking=True)
         self.loss_obj.stage_labels(lab)
 
-    def _allreduce_bucket(self, lo, hi):
+    def _allreduce_bucket(self, lo, hi, then_update=False, first=False):
         """enqueue the all-reduce (SUM) of grad[lo:hi] on the communication stream once everything enqueued so far on the main and
-        weight-gradient streams has finished; the optimizer waits for the handles in self._pending"""
+        weight-gradient streams has finished -- and, with ``then_update``, the optimizer launch of that range right behind it on the same
+        stream (the bucket is updated while the rest of the backward pass still runs); otherwise the optimizer waits for self._pending"""
         import torch.distributed as dist
         g = self.g
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.device)
+            for t in g.owned_tensors() + [t for t in vars(self.optimizer).values() if isinstance(t, torch.Tensor) and t.is_cuda]:
+                t.record_stream(self._comm_stream)
         cs = self._comm_stream
         cs.wait_stream(torch.cuda.current_stream(self.device))
         if g.wgrad_stream is not None:
             cs.wait_stream(g.wgrad_stream)
         with torch.cuda.stream(cs):
-            self._pending.append(dist.all_reduce(g.ps.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+            work = dist.all_reduce(g.ps.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            if then_update:
+                work.wait()                    # the communication stream waits for the collective
+                self.optimizer.launch_range(self, lo, hi, first)
+            else:
+                self._pending.append(work)
+
+    def _bucket_ready(self, lo, hi):
+        """engine callback (eager mode): the gradient range [lo, hi) is complete behind what is queued on the main and weight-gradient
+        streams.  Data parallel: all-reduce it, then update it, on the communication stream; single GPU: update it on the weight-gradient
+        stream.  Either way the bucket's RAdam + L2 launch overlaps the rest of the backward pass (reference north_star: all-reduce of
+        gradients overlapped with the RAdam update); only the last, ~1 % bucket (stem + stride-4 stage) is exposed."""
+        first, self._step_ranges = not self._step_ranges, self._step_ranges + [(lo, hi)]
+        if self.world_size > 1:
+            self._allreduce_bucket(lo, hi, then_update=True, first=first)
+            return
+        side = self.g.wgrad_stream
+        if side is None:
+            self.optimizer.launch_range(self, lo, hi, first)
+        else:
+            with torch.cuda.stream(side):
+                self.optimizer.launch_range(self, lo, hi, first)
 
     def run_step(self):
         """one training step on the staged batch; returns nothing (loss stays on the device in self.loss_value)"""
@@ -151,16 +178,31 @@ class YOLOv3Model(object):
                 self._capture()
             ga, gb = self._graphs
             dp = self.world_size > 1
+            if ga is None and self.bucket_updates and (self.overlap_allreduce or not dp):
+                # eager: every gradient bucket is (all-reduced and) updated as soon as it is complete, beside the rest of the backward pass
+                self._step_ranges = []
+                g.on_bucket = self._bucket_ready
+                try:
+                    self._fwd_bwd()
+                finally:
+                    g.on_bucket = None
+                main = torch.cuda.current_stream(self.device)
+                if self._comm_stream is not None and dp:
+                    main.wait_stream(self._comm_stream)
+                if g.wgrad_stream is not None:
+                    main.wait_stream(g.wgrad_stream)
+                covered = sum(hi - lo for lo, hi in self._step_ranges)
+                if covered != g.ps.n:
+                    raise RuntimeError('gradient buckets cover %d of %d parameters' % (covered, g.ps.n))
+                self.optimizer.finish(self)
+                g.refresh_dgrad_async()
+                return
             if ga is None:
-                overlap = dp and self.overlap_allreduce and bool(g.buckets)
-                g.on_bucket = self._allreduce_bucket if overlap else None       # called with (lo, hi) as each stage's gradients are complete
                 self._fwd_bwd()
-                if dp:
-                    self._allreduce_bucket(0, g.bucket_tail if overlap and g.bucket_tail else g.ps.n)
             else:
                 ga.replay()
-                if dp:
-                    self._allreduce_bucket(0, g.ps.n)
+            if dp:
+                self._allreduce_bucket(0, g.ps.n)
             for work in self._pending:
                 work.wait()                    # the current stream waits for the collective
             self._pending = []

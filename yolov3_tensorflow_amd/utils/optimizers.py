@@ -45,7 +45,8 @@ class FlatOptimizer(object):
             self.sched = torch.tensor([self._lr, 0.0, 0.0, 0.0], device=dev)
             self._iterations = torch.zeros(1, dtype=torch.int64, device=dev)
             self.vhat = torch.zeros(ps.n, device=dev) if self.amsgrad else None
-            self.l2_partial = torch.zeros(ops.radam_l2_blocks(ps.n), device=dev)
+            self.l2_partial = torch.zeros(4 * 2048 + ops.radam_l2_blocks(ps.n), device=dev)     # a region per range launched in one step
+            self._cursor = 0
             self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)      # waves that met an inf / NaN gradient element
 
     # betas / epsilon handed to the update kernel (SGD: beta_1 carries the momentum)
@@ -56,16 +57,34 @@ class FlatOptimizer(object):
         b1, b2, _ = self._coefficients()
         ops.optimizer_schedule(self.sched, self._iterations, self.KIND, b1, b2, self.initial_decay)
 
-    def launch(self, model):
+    def launch_range(self, model, lo, hi, first):
+        """the update of the parameter range [lo, hi) (a gradient bucket: slots are 256-element aligned) on the current stream; ``first``
+        marks the first range of a step (advances the step counter / schedule scalars once)"""
         ps = model.g.ps
-        self.launch_schedule()
+        if first:
+            self.launch_schedule()
+            self._cursor = 0
         b1, b2, eps = self._coefficients()
-        ops.radam_l2_step(ps.flat, ps.grad, ps.m, ps.v, ps.l2_table, ps.n, self.sched, b1, b2, eps,
-                          grad_scale=1.0 / (model.world_size * backend.loss_scale()), zero_grad=True, params_bf16=ps.bf16, vhat=self.vhat,
-                          l2_partial=self.l2_partial, nonfinite=self.nonfinite)
-        # reported loss = YOLOv3 loss + sum of L2 regularisers (what keras' compiled loss contains)
-        ops.sum_partials(self.l2_partial, self.l2_partial.numel(), None, model.l2_value)
-        ops.sum_partials(self.l2_partial, self.l2_partial.numel(), model.loss_obj.total, model.loss_value)
+        n = hi - lo
+        blocks = ops.radam_l2_blocks(n)
+        part = self.l2_partial[self._cursor:self._cursor + blocks]
+        if part.numel() < blocks:
+            raise RuntimeError('l2_partial exhausted: too many optimizer ranges in one step')
+        self._cursor += blocks
+        sl = slice(lo, hi)
+        ops.radam_l2_step(ps.flat[sl], ps.grad[sl], ps.m[sl], ps.v[sl], ps.l2_table[lo // 256:hi // 256], n, self.sched, b1, b2, eps,
+                          grad_scale=1.0 / (model.world_size * backend.loss_scale()), zero_grad=True, params_bf16=ps.bf16[sl],
+                          vhat=None if self.vhat is None else self.vhat[sl], l2_partial=part, nonfinite=self.nonfinite)
+
+    def finish(self, model):
+        """reported loss = YOLOv3 loss + sum of L2 regularisers (what keras' compiled loss contains), from the ranges launched this step"""
+        ops.sum_partials(self.l2_partial, self._cursor, None, model.l2_value)
+        ops.sum_partials(self.l2_partial, self._cursor, model.loss_obj.total, model.loss_value)
+
+    def launch(self, model):
+        """the whole update in one launch (hipGraph replay, tests); the training step launches it per gradient bucket (launch_range)"""
+        self.launch_range(model, 0, model.g.ps.n, True)
+        self.finish(model)
 
 
 class SGD(FlatOptimizer):
