@@ -62,11 +62,33 @@ def build_model(backbone, H, W, N, class_num, device, focal=False):
     return model, loss, opt, grids
 
 
-def conv_kernel_roofline(model, steps):
-    """Achieved TFLOP/s of the dominant kernel, conv3x3_strip_kernel (every 3x3 / stride-1 convolution forward and data gradient of the
-    step; the remaining stem / stride-2 / 1x1 launches run igemm_fwd_kernel and are reported beside it), measured with HIP events on
-    the launch stream in an eager pass with the weight-gradient stream folded into the main stream: sum of algorithmic FLOPs of the
-    launches / sum of their durations."""
+HBM_PEAK_GBS = 8000.0              # HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming kernel sustains on it
+HBM_ACHIEVABLE_GBS = 6300.0
+
+
+def _big_tensor_bytes(args, kwargs, floor):
+    """operand bytes of a bandwidth-bound launch: every tensor argument of at least ``floor`` bytes counted once (its read or its write)"""
+    seen, total = set(), 0
+    for t in list(args) + list(kwargs.values()):
+        if isinstance(t, (list, tuple)):
+            ts = t
+        else:
+            ts = (t,)
+        for u in ts:
+            if isinstance(u, torch.Tensor) and u.data_ptr() not in seen and u.numel() * u.element_size() >= floor:
+                seen.add(u.data_ptr())
+                total += u.numel() * u.element_size()
+    return total
+
+
+def kernel_rooflines(model, steps, overlap):
+    """HIP-event timing (on the launch stream) of the step's kernel families in eager passes:
+      strip / other : conv3x3_strip_kernel (every 3x3 stride-1 conv forward + data gradient: the dominant kernel) and igemm_fwd_kernel (stem,
+                      stride-2, 1x1, fused concat) -- algorithmic FLOPs / duration
+      bn_fwd / bn_bwd / loss / optimizer : the bandwidth-bound families -- bytes of their full-size operands / duration
+    ``overlap`` False: the weight-gradient stream is folded into the main stream, every launch is timed alone (the kernel's own speed).
+    ``overlap`` True: the real two-stream schedule -- a launch's interval then also contains what the concurrent weight-gradient kernels take
+    from it (the in-step figure).  Collective-free, so data-parallel runs call it on every rank."""
     from yolov3_tensorflow_amd import ops
     records = []
 
@@ -74,35 +96,57 @@ def conv_kernel_roofline(model, steps):
         return (p.R == 3 and p.S == 3 and p.stride == 1 and p.pad_t == 1 and p.pad_l == 1 and p.C0 == 0 and p.Ho == p.H and p.Wo == p.W
                 and p.Cin % 64 == 0 and p.Cout % 64 == 0)
 
-    def timed(fn):
+    def timed_conv(fn):
         def wrapper(p, *a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn(p, *a, **k)
             e1.record()
             cin = 3 if p.Cin == 8 else p.Cin     # algorithmic: the RGB stem is 3 of the 8 padded channels
-            records.append((e0, e1, 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S, is_strip(p) and k.get('bias') is None))
+            records.append((e0, e1, 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S, 'strip' if (is_strip(p) and k.get('bias') is None) else 'other'))
         return wrapper
 
-    ops_fwd, ops_dg = ops.conv2d_fwd, ops.conv2d_dgrad
-    ops.conv2d_fwd, ops.conv2d_dgrad = timed(ops_fwd), timed(ops_dg)
-    saved, saved_bucket = model.overlap_wgrad, model.g.on_bucket
-    model.overlap_wgrad = False        # time each launch alone on the stream (no weight-gradient GEMM sharing the CUs)
-    model.g.on_bucket = None           # purely local passes: no gradient all-reduce is issued (data-parallel runs call this on every rank)
+    def timed_bytes(fn, family, nbytes=None):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            records.append((e0, e1, float(nbytes(a, k) if nbytes else _big_tensor_bytes(a, k, 1 << 16)), family))
+            return r
+        return wrapper
+
+    n_params = model.g.ps.n
+    patched = {'conv2d_fwd': timed_conv(ops.conv2d_fwd), 'conv2d_dgrad': timed_conv(ops.conv2d_dgrad)}
+    for name in ('bn_act_fwd', 'bn_pool_fwd'):
+        patched[name] = timed_bytes(getattr(ops, name), 'bn_fwd')
+    for name in ('bn_act_bwd_fused', 'bn_act_bwd_reduce', 'bn_act_bwd_apply', 'bn_pool_bwd_reduce', 'bn_pool_bwd_apply'):
+        patched[name] = timed_bytes(getattr(ops, name), 'bn_bwd')
+    patched['loss_fwd_bwd'] = timed_bytes(ops.loss_fwd_bwd, 'loss')
+    # p, g, m, v read + p, m, v written + the 16-bit copy = 30 B / parameter (SURVEY 8d counts 28 without the copy; the gradient zeroing adds 4 more)
+    patched['radam_l2_step'] = timed_bytes(ops.radam_l2_step, 'optimizer', nbytes=lambda a, k: 30.0 * a[5])
+    saved = {n: getattr(ops, n) for n in patched}
+    saved_overlap, saved_bucket = model.overlap_wgrad, model.g.on_bucket
+    for n, f in patched.items():
+        setattr(ops, n, f)
+    model.overlap_wgrad = bool(overlap)
+    model.g.on_bucket = None           # purely local passes: no gradient all-reduce is issued
     try:
         for _ in range(steps):
             model._fwd_bwd()
             model._update()
         torch.cuda.synchronize()
     finally:
-        ops.conv2d_fwd, ops.conv2d_dgrad = ops_fwd, ops_dg
-        model.overlap_wgrad, model.g.on_bucket = saved, saved_bucket
+        for n, f in saved.items():
+            setattr(ops, n, f)
+        model.overlap_wgrad, model.g.on_bucket = saved_overlap, saved_bucket
     out = {}
-    for name, sel in (('strip', True), ('other', False)):
-        rs = [r for r in records if r[3] == sel]
+    for family in ('strip', 'other', 'bn_fwd', 'bn_bwd', 'loss', 'optimizer'):
+        rs = [r for r in records if r[3] == family]
         t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rs)
-        fl = sum(r[2] for r in rs)
-        out[name] = (fl / (t_ms * 1e-3) / 1e12 if rs else 0.0, t_ms / max(len(rs), 1), len(rs) // max(steps, 1))
+        work = sum(r[2] for r in rs)
+        out[family] = {'rate': work / (t_ms * 1e-3) if rs and t_ms > 0 else 0.0, 'avg_launch_ms': t_ms / max(len(rs), 1),
+                       'launches_per_step': len(rs) // max(steps, 1), 'ms_per_step': t_ms / max(steps, 1), 'work_per_step': work / max(steps, 1)}
     return out
 
 
@@ -124,22 +168,52 @@ def strip_hbm_traffic():
     return None, 'no PMC summary committed'
 
 
-def cpu_baseline(H, W, class_num, budget_batch=4):
-    """the CPU oracle (a restatement of the reference step on PyTorch-CPU, NOT TensorFlow) timed on this host's cores"""
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or 'unknown'
+
+
+def _time_oracle(H, W, class_num, batch, anchors, budget_s, max_steps):
     from oracle.train import OracleTrainer
     grids = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
-    images, labels = synthetic_batch(budget_batch, H, W, class_num, 0)
-    o = OracleTrainer('resnet-18', grids, class_num, COCO_ANCHORS, 0.8, LOSS_WEIGHTS, rectified_coord_num=-1)
+    images, labels = synthetic_batch(batch, H, W, max(class_num, 1), 0)
+    o = OracleTrainer('resnet-18', grids, class_num, anchors, 0.8, LOSS_WEIGHTS, rectified_coord_num=-1)
     o.ensure_params(images.numpy())
     o.step(images.numpy(), labels.numpy())        # warm-up step (allocations, thread pools)
     n_steps, t0 = 0, time.time()
-    while n_steps < 12 and (time.time() - t0 < 12.0 or n_steps < 2):     # ~10-20 s of CPU work
+    while n_steps < max_steps and (time.time() - t0 < budget_s or n_steps < 1):
         o.step(images.numpy(), labels.numpy())
         n_steps += 1
-    dt = (time.time() - t0) / n_steps
-    return {'value': round(budget_batch / dt, 3), 'unit': 'images/sec', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-            'sample': '%d timed step(s) of batch %d at %dx%d, %d classes (PyTorch-CPU float32 restatement of the reference step; '
-                      'host has %d logical cpus)' % (n_steps, budget_batch, H, W, class_num, os.cpu_count() or 0)}
+    return batch / ((time.time() - t0) / n_steps), n_steps
+
+
+def cpu_baseline(H, W, class_num, budget_batch=4):
+    """the CPU oracle (a restatement of the reference step on PyTorch-CPU, NOT TensorFlow) timed on this host's cores: the bench workload's
+    shape at a small batch on all threads (the headline value), the same on ONE thread, and BASELINE.json configs[0] (320x320, batch 2, 13
+    classes, the reference's 3/2/3 anchors) on all threads"""
+    from yolov3_tensorflow_amd.configs import FLAGS
+    threads = int(torch.get_num_threads())
+    ips, n_steps = _time_oracle(H, W, class_num, budget_batch, COCO_ANCHORS, 10.0, 12)
+    c1_ips, c1_steps = _time_oracle(320, 320, 13, 2, FLAGS.anchor_boxes, 4.0, 8)
+    torch.set_num_threads(1)
+    try:
+        st_ips, st_steps = _time_oracle(H, W, class_num, 1, COCO_ANCHORS, 5.0, 2)
+    finally:
+        torch.set_num_threads(threads)
+    return {'value': round(ips, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'cpu_model': _cpu_model(),
+            'logical_cpus': os.cpu_count() or 0,
+            'single_thread': {'value': round(st_ips, 4), 'unit': 'images/sec', 'cores': 1, 'sample': '%d timed step(s) of batch 1 at %dx%d' % (st_steps, H, W)},
+            'config1': {'value': round(c1_ips, 3), 'unit': 'images/sec', 'cores': threads,
+                        'sample': '%d timed step(s) of BASELINE.json configs[0]: 320x320, batch 2, 13 classes, anchors 3/2/3' % c1_steps},
+            'sample': '%d timed step(s) of batch %d at %dx%d, %d classes (PyTorch-CPU float32 restatement of the reference step on %s; '
+                      'host has %d logical cpus)' % (n_steps, budget_batch, H, W, class_num, _cpu_model(), os.cpu_count() or 0)}
 
 
 def main():
@@ -161,6 +235,7 @@ def main():
     ap.add_argument('--focal', action='store_true', help='focal loss on (BASELINE.json configs[4])')
     ap.add_argument('--wgrad-batch', type=int, default=None, help='weight gradients per hand-off to the side stream (engine default 4)')
     ap.add_argument('--wgrad-gflop', type=float, default=None, help='also hand over when the pending weight gradients reach this many GFLOP')
+    ap.add_argument('--no-bucket-updates', action='store_true', help='one RAdam + L2 launch after the backward pass instead of one per gradient bucket')
     ap.add_argument('--no-fused-bn', action='store_true', help='three-kernel BatchNorm backward instead of the single-launch one')
     args = ap.parse_args()
 
@@ -189,6 +264,7 @@ def main():
     model.use_hip_graph = bool(args.graph)
     model.overlap_wgrad = not args.no_overlap
     model.g.fused_bn_bwd = not args.no_fused_bn
+    model.bucket_updates = not args.no_bucket_updates
     if args.wgrad_batch is not None:
         model.g.wgrad_batch = max(1, args.wgrad_batch)
     if args.wgrad_gflop is not None:
@@ -243,17 +319,37 @@ def main():
         out['step_mfma_frac'] = round(out['step_tflops'] / PEAK_BF16_TFLOPS, 4)
     if not args.no_roofline:
         # every rank runs the (collective-free) measurement passes so that the ranks stay in step; rank 0 reports its own numbers
-        rf = conv_kernel_roofline(model, max(2, min(5, args.steps)))
+        k = max(2, min(5, args.steps))
+        alone = kernel_rooflines(model, k, overlap=False)
+        instep = kernel_rooflines(model, k, overlap=True)
     if rank == 0 and not args.no_roofline:
-        tf, avg_ms, per_step = rf['strip']
         traffic, traffic_src = strip_hbm_traffic()
+        tf = alone['strip']['rate'] / 1e12
+        tf_in = instep['strip']['rate'] / 1e12
         out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel (3x3 stride-1 conv forward + data-gradient launches, all tile variants)',
                            'achieved': round(tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_TFLOPS, 4),
                            'traffic': traffic, 'traffic_unit': 'bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), ' + traffic_src,
-                           'avg_launch_ms': round(avg_ms, 5), 'launches_per_step': per_step,
+                           'avg_launch_ms': round(alone['strip']['avg_launch_ms'], 5), 'launches_per_step': alone['strip']['launches_per_step'],
+                           'timing': 'each launch alone on the stream (weight-gradient stream folded away); in_step = the same launches under the '
+                                     'two-stream schedule the headline runs, where concurrent weight-gradient kernels share the CUs',
+                           'in_step': {'achieved': round(tf_in, 2), 'frac': round(tf_in / PEAK_BF16_TFLOPS, 4),
+                                       'avg_launch_ms': round(instep['strip']['avg_launch_ms'], 5)},
                            'other_conv': {'kernel': 'igemm_fwd_kernel (stem, stride-2, 1x1, fused-concat launches)',
-                                          'achieved': round(rf['other'][0], 2), 'avg_launch_ms': round(rf['other'][1], 5),
-                                          'launches_per_step': rf['other'][2]}}
+                                          'achieved': round(alone['other']['rate'] / 1e12, 2), 'in_step_achieved': round(instep['other']['rate'] / 1e12, 2),
+                                          'avg_launch_ms': round(alone['other']['avg_launch_ms'], 5),
+                                          'launches_per_step': alone['other']['launches_per_step']}}
+        names = {'bn_fwd': 'bn_act_fwd / bn_pool_fwd (BatchNorm apply + ReLU + residual, stem BN + max-pool)',
+                 'bn_bwd': 'bn_bwd_fused / bn_bwd_reduce + apply / pooled variants (BatchNorm backward)',
+                 'loss': 'loss_assign + loss_main + loss_finalize (YOLOv3 loss forward + d(logits))',
+                 'optimizer': 'radam_l2_kernel (RAdam + L2, 30 B / parameter)'}
+        out['hbm'] = {'peak': HBM_PEAK_GBS, 'achievable': HBM_ACHIEVABLE_GBS, 'unit': 'GB/s',
+                      'bytes': 'operand bytes of the launches (every full-size tensor argument once), not PMC traffic'}
+        for fam, label in names.items():
+            a, b = alone[fam], instep[fam]
+            out['hbm'][fam] = {'kernel': label, 'achieved': round(a['rate'] / 1e9, 1), 'frac_of_achievable': round(a['rate'] / 1e9 / HBM_ACHIEVABLE_GBS, 4),
+                               'in_step_achieved': round(b['rate'] / 1e9, 1), 'ms_per_step': round(a['ms_per_step'], 4),
+                               'in_step_ms_per_step': round(b['ms_per_step'], 4), 'launches_per_step': a['launches_per_step'],
+                               'MB_per_step': round(a['work_per_step'] / 1e6, 1)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(H, W, args.classes)
     if rank == 0:

@@ -34,6 +34,9 @@ int yolo_abi_version(void);
  * compiled with -DYOLO_FP16: wherever this header says "bf16" that library stores IEEE half and multiplies with the f16 MFMA). */
 int yolo_abi_dtype(void);
 const char* yolo_last_error(void);
+/* CRC-32C (Castagnoli) of a host buffer, continuing from `seed` (0 to start): the checksum of the TensorFlow checkpoint files the
+ * reference reads / writes through TensorFlow (/root/reference/yolov3/trainer.py:47-67,90-91; utils/tf_checkpoint.py here). */
+uint32_t yolo_crc32c(const void* data, size_t n, uint32_t seed);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA (v_mfma_f32_16x16x32_bf16), NHWC.

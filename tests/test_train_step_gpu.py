@@ -315,7 +315,8 @@ def test_full_state_checkpoint_resumes_bit_exactly(tmp_path):
     steps(a, 3)
     stem = str(tmp_path / 'ck' / 'lp-recognition-test-  3- 1.00000.ckpt')
     a.save_weights(stem, full_state=True, epoch=2)
-    assert sorted(os.listdir(tmp_path / 'ck')) == ['checkpoint', os.path.basename(stem) + '.npz', os.path.basename(stem) + '.state.npz']
+    assert sorted(os.listdir(tmp_path / 'ck')) == ['checkpoint', os.path.basename(stem) + '.data-00000-of-00001', os.path.basename(stem) + '.index',
+                                                   os.path.basename(stem) + '.state.npz']      # TensorFlow's checkpoint files + the opt-in state
     steps(a, 3)
     want = a.g.ps.flat.clone()
 

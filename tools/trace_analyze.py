@@ -6,8 +6,8 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '')))
 rows.sort()
-# steps are delimited by radam_schedule_kernel launches
-idx = [i for i, r in enumerate(rows) if 'radam_schedule' in r[2]]
+# steps are delimited by pack_input_kernel launches (the first kernel of a step; the optimizer runs per gradient bucket inside the backward pass)
+idx = [i for i, r in enumerate(rows) if 'pack_input' in r[2]]
 print('kernels %d, steps %d' % (len(rows), len(idx)))
 a, b = idx[-3], idx[-2]          # one full steady-state step: [schedule_k .. schedule_k+1)
 step = rows[a:b]

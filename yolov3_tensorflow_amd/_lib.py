@@ -49,6 +49,7 @@ SIGNATURES = {
     'yolo_abi_version': (I, []),
     'yolo_abi_dtype': (I, []),
     'yolo_last_error': (C.c_char_p, []),
+    'yolo_crc32c': (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
     'yolo_conv2d_stat_rows': (I, [CP]),
     'yolo_set_tuning': (I, [C.c_char_p, I]),
     'yolo_conv2d_fwd': (I, [CP, P, P, P, P, P, I, P, P, P]),

@@ -684,9 +684,10 @@ class MixConvOp(object):
         y.buf = y.cell['t']
         y.dy = y.dy_cell['t']
         ps = g.ps
-        pad = [None] * (4 - len(y.wps))                      # a lone DepthwiseConv2D has one (non-empty) channel group
-        self.w = [ps.view(wp, ps.bf16) for wp in y.wps] + pad
-        self.dw = [ps.view(wp, ps.grad) for wp in y.wps] + pad
+        self.w = [ps.view(wp, ps.bf16) for wp in y.wps]
+        self.dw = [ps.view(wp, ps.grad) for wp in y.wps]
+        self.w += self.w[:1] * (4 - len(self.w))             # a lone DepthwiseConv2D has one (non-empty) channel group: the empty groups'
+        self.dw += self.dw[:1] * (4 - len(self.dw))          # pointers are never dereferenced, but the C-ABI wants them non-null
         C = y.shape[3]
         self.P = ops.reduce_rows(y.M, C)
         self.part = torch.zeros(self.P, 2, C, device=g.dev)

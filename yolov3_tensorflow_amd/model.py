@@ -7,7 +7,6 @@ is a fixed sequence of kernel launches on one HIP stream, captured once into a h
     pack input -> forward -> loss fwd+bwd -> backward -> [RCCL all-reduce of the flat gradient] -> RAdam+L2 -> weight repack
 """
 import os
-import json
 import numpy as np
 import torch
 from . import engine, ops
@@ -360,16 +359,17 @@ class YOLOv3Model(object):
             torch.cuda.synchronize(self.device)
 
     def save_weights(self, path, full_state=False, epoch=None):
-        """weights-only checkpoint under the reference's file stem (trainer.py:90-91).  The TF SSTable byte format cannot be
-        produced without TensorFlow: variables are stored by Keras name in ``<path>.npz`` and a TF-style
-        ``checkpoint`` pointer file names the latest stem.
+        """weights-only checkpoint under the reference's file stem (trainer.py:90-91: ``model.save_weights('...ckpt')``) in TensorFlow's
+        checkpoint byte format -- ``<path>.index`` (SSTable) + ``<path>.data-00000-of-00001`` with Keras' object-based keys and object graph,
+        and the ``checkpoint`` state file naming the latest stem (utils/tf_checkpoint.py; parity unpinned against TensorFlow itself).
         ``full_state`` (opt-in; the reference restores weights only, so the RAdam moments, its step counter, the rectified-loss image
         counter and the epoch -- hence the learning-rate schedule -- restart) additionally writes
         ``<path>.state.npz`` with exactly those, in the flat device layout of this build."""
+        from .utils import tf_checkpoint
         d = os.path.dirname(path)
         if d and not os.path.exists(d):
             os.makedirs(d)
-        np.savez(path + '.npz', **self.get_weights())
+        tf_checkpoint.write_checkpoint(path, self.get_weights())
         if full_state:
             ps, opt = self.g.ps, self.optimizer
             state = {'layout_n': np.int64(ps.n), 'm': ps.m.detach().cpu().numpy(), 'v': ps.v.detach().cpu().numpy(),
@@ -379,14 +379,20 @@ class YOLOv3Model(object):
             if opt is not None and opt.vhat is not None:
                 state['vhat'] = opt.vhat.detach().cpu().numpy()
             np.savez(path + '.state.npz', **state)
-        with open(os.path.join(d, 'checkpoint'), 'w') as f:
-            f.write('model_checkpoint_path: %s\n' % json.dumps(os.path.basename(path)))
+        tf_checkpoint.update_checkpoint_state(d, os.path.basename(path))
 
     def load_weights(self, path, full_state=False):
         """-> the epoch stored with a full-state checkpoint (or None)"""
-        stem = path[:-4] if path.endswith('.npz') else path
-        with np.load(stem + '.npz', allow_pickle=False) as z:
-            self.set_weights({k: z[k] for k in z.files})
+        from .utils import tf_checkpoint
+        stem = path
+        for suffix in ('.npz', '.index'):
+            if stem.endswith(suffix):
+                stem = stem[:-len(suffix)]
+        if tf_checkpoint.exists(stem):                     # TensorFlow checkpoint: ours, or one written by the reference through TensorFlow
+            self.set_weights(tf_checkpoint.read_checkpoint(stem))
+        else:                                              # round-1 checkpoints of this package (variables by Keras name in an .npz)
+            with np.load(stem + '.npz', allow_pickle=False) as z:
+                self.set_weights({k: z[k] for k in z.files})
         if not full_state or not os.path.exists(stem + '.state.npz'):
             return None
         if self.optimizer is None or self.loss_obj is None:
@@ -411,14 +417,9 @@ class YOLOv3Model(object):
 
 
 def latest_checkpoint(directory):
-    """tf.train.latest_checkpoint semantics (reference trainer.py:60): read the ``checkpoint`` pointer file"""
-    ptr = os.path.join(directory, 'checkpoint')
-    if not os.path.exists(ptr):
+    """tf.train.latest_checkpoint semantics (reference trainer.py:60): the stem named by the ``checkpoint`` state file, if its files exist"""
+    from .utils import tf_checkpoint
+    full = tf_checkpoint.latest_checkpoint(directory)
+    if full is None:
         return None
-    with open(ptr) as f:
-        line = f.readline().strip()
-    if not line.startswith('model_checkpoint_path:'):
-        return None
-    stem = json.loads(line.split(':', 1)[1].strip())
-    full = os.path.join(directory, stem)
-    return full if os.path.exists(full + '.npz') else None
+    return full if (tf_checkpoint.exists(full) or os.path.exists(full + '.npz')) else None

@@ -39,7 +39,7 @@ class YOLOv3Trainer(object):
         self.checkpoint_path = FLAGS.checkpoint_path
         if self.checkpoint_path is None:
             self.checkpoint_path = 'models/'
-        if os.path.isfile(self.checkpoint_path) or os.path.isfile(self.checkpoint_path + '.npz'):
+        if any(os.path.isfile(self.checkpoint_path + ext) for ext in ('', '.index', '.npz')):
             self.model.load_weights(self.checkpoint_path)
             self._resumed_from = self.checkpoint_path
             logging.info('weights loaded')
