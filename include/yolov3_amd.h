@@ -34,6 +34,22 @@ int yolo_abi_version(void);
  * compiled with -DYOLO_FP16: wherever this header says "bf16" that library stores IEEE half and multiplies with the f16 MFMA). */
 int yolo_abi_dtype(void);
 const char* yolo_last_error(void);
+/* ------------------------------------------------------------------------------------------------------------------
+ * Launch sequencer.  The reference runs a training step as ONE session.run of a graph TensorFlow built once
+ * (/root/reference/yolov3/trainer.py:84,113: compile + fit); here the step is a fixed list of ~270 kernel launches over static buffers on
+ * two or three streams.  Between yolo_seq_begin() and yolo_seq_end() every launch made through this library (and every yolo_seq_fork) is
+ * executed AND recorded -- kernel, grid, block, LDS bytes, stream, a copy of the argument values; yolo_seq_run(id, begin, end) re-issues
+ * items [begin, end) with one call (the host cost of a step drops from ~2.8 ms of Python + ctypes to the bare HIP launches).
+ * yolo_seq_mark() = number of items recorded so far (segment boundary for host work that must happen between launches, e.g. a collective).
+ * yolo_seq_fork(a, b): stream b waits for everything queued on stream a at this point (event record + stream wait; usable outside a
+ * recording too).  One recording at a time, single-threaded; the caller re-records when any buffer address or launch decision changes.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int yolo_seq_begin(void);                 /* -> sequence id */
+int yolo_seq_mark(void);
+int yolo_seq_end(void);                   /* -> number of items */
+int yolo_seq_fork(void* from_stream, void* to_stream);
+int yolo_seq_run(int seq, int begin, int end);
+int yolo_seq_free(int seq);
 /* CRC-32C (Castagnoli) of a host buffer, continuing from `seed` (0 to start): the checksum of the TensorFlow checkpoint files the
  * reference reads / writes through TensorFlow (/root/reference/yolov3/trainer.py:47-67,90-91; utils/tf_checkpoint.py here). */
 uint32_t yolo_crc32c(const void* data, size_t n, uint32_t seed);

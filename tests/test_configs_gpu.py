@@ -140,3 +140,38 @@ def test_validation_pass_updates_nothing_but_the_image_counter():
     assert opt.iterations == it0 and int(loss.current_num.item()) == n0 + N
     assert np.isfinite(val) and abs(val - train_loss) < 0.05 * abs(train_loss)      # same batch, weights one 1e-5 step further
     assert model.g.bn_momentum == 0.9 and model.g.training
+
+
+def test_native_launch_sequencer_replays_the_step_bit_exactly():
+    """after two plain steps the third is recorded by the library (every launch + cross-stream edge of the three-stream schedule) and the
+    following ones are re-issued with one native call (yolo_seq_run): 7 steps with the sequencer == 7 steps of plain eager launches, bit for
+    bit (the kernels are deterministic); a learning-rate change between steps is honoured (it lives in device memory), and a change of a
+    launch decision drops the recording"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from test_train_step_gpu import build, make_batch
+    H = W = 160
+    N, T, Cn = 4, 3, 4
+    batches = [make_batch(N, H, W, T, Cn, seed=30 + i) for i in range(2)]
+    out = []
+    for native in (True, False):
+        model, loss, opt, grids = build('resnet-18', H, W, N, Cn, rect=12)
+        model.native_sequencer = native
+        curve = []
+        for step in range(7):
+            opt.lr = 1e-5 if step < 5 else 1e-4
+            curve.append(model.train_on_batch(*batches[step % 2]))
+        torch.cuda.synchronize()
+        out.append((curve, model.g.ps.flat.clone(), model.g.ps.m.clone(), model.g.bns[5].moving_var.clone(), int(loss.current_num.item()), opt.iterations))
+        if native:
+            assert model._seq is not None and len(model._seq[2]) == 1 and model._seq[2][0][0] > 150       # one segment: the whole step
+            sid = model._seq[0]
+            model.g.wgrad_batch = 2                      # a launch decision changes: the next step re-records after running plain
+            model.train_on_batch(*batches[0])
+            assert model._seq is None
+        else:
+            assert model._seq is None
+            model.train_on_batch(*batches[0])
+    (c0, w0, m0, v0, n0, i0), (c1, w1, m1, v1, n1, i1) = out
+    assert c0 == c1, (c0, c1)
+    assert torch.equal(w0, w1) and torch.equal(m0, m1) and torch.equal(v0, v1) and (n0, i0) == (n1, i1) == (28, 7)

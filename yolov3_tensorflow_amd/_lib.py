@@ -50,6 +50,12 @@ SIGNATURES = {
     'yolo_abi_dtype': (I, []),
     'yolo_last_error': (C.c_char_p, []),
     'yolo_crc32c': (C.c_uint32, [C.c_void_p, C.c_size_t, C.c_uint32]),
+    'yolo_seq_begin': (I, []),
+    'yolo_seq_mark': (I, []),
+    'yolo_seq_end': (I, []),
+    'yolo_seq_fork': (I, [P, P]),
+    'yolo_seq_run': (I, [I, I, I]),
+    'yolo_seq_free': (I, [I]),
     'yolo_conv2d_stat_rows': (I, [CP]),
     'yolo_set_tuning': (I, [C.c_char_p, I]),
     'yolo_conv2d_fwd': (I, [CP, P, P, P, P, P, I, P, P, P]),

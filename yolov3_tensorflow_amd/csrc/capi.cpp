@@ -54,3 +54,75 @@ extern "C" uint32_t yolo_crc32c(const void* data, size_t n, uint32_t seed) {
   while (n--) c = g_crc_tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
   return ~c;
 }
+
+// ---- launch sequencer (launch.h) ----
+static YoloSeq* g_seq_rec = nullptr;
+static std::vector<YoloSeq*> g_seqs;
+YoloSeq* yolo_seq_recording() { return g_seq_rec; }
+
+extern "C" int yolo_seq_begin(void) {
+  YOLO_CHECK_ARG(g_seq_rec == nullptr, "a sequence is already being recorded");
+  g_seq_rec = new YoloSeq();
+  g_seqs.push_back(g_seq_rec);
+  return (int)g_seqs.size() - 1;
+}
+
+extern "C" int yolo_seq_mark(void) { return g_seq_rec ? (int)g_seq_rec->items.size() : YOLO_ERR_INVALID_ARG; }
+
+extern "C" int yolo_seq_end(void) {
+  YOLO_CHECK_ARG(g_seq_rec != nullptr, "no sequence is being recorded");
+  const int n = (int)g_seq_rec->items.size();
+  g_seq_rec = nullptr;
+  return n;
+}
+
+extern "C" int yolo_seq_fork(void* from_stream, void* to_stream) {
+  hipEvent_t ev;
+  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) { yolo_set_error("hipEventCreateWithFlags: %s", hipGetErrorString(e)); return (int)e; }
+  if ((e = hipEventRecord(ev, (hipStream_t)from_stream)) != hipSuccess || (e = hipStreamWaitEvent((hipStream_t)to_stream, ev, 0)) != hipSuccess) {
+    yolo_set_error("yolo_seq_fork: %s", hipGetErrorString(e));
+    (void)hipEventDestroy(ev);
+    return (int)e;
+  }
+  if (g_seq_rec) {                                   // the sequence keeps the event: the edge is replayed on it
+    YoloSeqItem rec; rec.kind = 1; rec.fn = nullptr; rec.lds = 0; rec.stream = (hipStream_t)from_stream; rec.event = ev;
+    YoloSeqItem wait = rec; wait.kind = 2; wait.stream = (hipStream_t)to_stream;
+    g_seq_rec->items.push_back(rec);
+    g_seq_rec->items.push_back(wait);
+    g_seq_rec->events.push_back(ev);
+  } else {
+    (void)hipEventDestroy(ev);                       // released by the runtime once the recorded work has completed
+  }
+  return YOLO_OK;
+}
+
+extern "C" int yolo_seq_run(int seq, int begin, int end) {
+  YOLO_CHECK_ARG(seq >= 0 && seq < (int)g_seqs.size() && g_seqs[seq] && g_seqs[seq] != g_seq_rec, "bad sequence id");
+  YoloSeq& s = *g_seqs[seq];
+  YOLO_CHECK_ARG(begin >= 0 && begin <= end && end <= (int)s.items.size(), "bad item range");
+  void* ptrs[64];
+  for (int i = begin; i < end; ++i) {
+    YoloSeqItem& it = s.items[i];
+    hipError_t e;
+    if (it.kind == 0) {
+      const size_t n = it.offs.size();
+      for (size_t k = 0; k < n; ++k) ptrs[k] = it.blob.data() + it.offs[k];
+      e = hipLaunchKernel(it.fn, it.grid, it.block, ptrs, it.lds, it.stream);
+    } else if (it.kind == 1) {
+      e = hipEventRecord(it.event, it.stream);
+    } else {
+      e = hipStreamWaitEvent(it.stream, it.event, 0);
+    }
+    if (e != hipSuccess) { yolo_set_error("yolo_seq_run: item %d: %s", i, hipGetErrorString(e)); return (int)e; }
+  }
+  return YOLO_OK;
+}
+
+extern "C" int yolo_seq_free(int seq) {
+  YOLO_CHECK_ARG(seq >= 0 && seq < (int)g_seqs.size() && g_seqs[seq] && g_seqs[seq] != g_seq_rec, "bad sequence id");
+  for (hipEvent_t ev : g_seqs[seq]->events) (void)hipEventDestroy(ev);
+  delete g_seqs[seq];
+  g_seqs[seq] = nullptr;
+  return YOLO_OK;
+}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/yolov3_amd.h"
+#include "launch.h"
 
 // The 16-bit activation / compute-copy element.  Default build: bfloat16.  -DYOLO_FP16 (libyolov3_amd_fp16.so): IEEE half -- same
 // kernels, same layouts; only the conversions below and the MFMA opcode differ.  The names keep "bf16" in both builds.

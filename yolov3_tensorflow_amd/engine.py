@@ -190,6 +190,7 @@ class Graph(object):
         self.bn_groups = []      # allocation units: a BNState or a MultiBN
         self.fwd, self.bwd = [], []
         self.training = True
+        self.capturing = False             # inside a hipGraph capture (model._capture): cross-stream edges must be torch's capture-aware ones
         self.bn_momentum = BN_MOMENTUM     # 1.0 while evaluating with batch statistics: the moving averages then stay as they are
         self._alloc = []
         self._repack_table = None
@@ -486,7 +487,8 @@ class Graph(object):
         backward kernels and the tails of the data-gradient GEMMs.  Under hipGraph capture this becomes a forked graph."""
         side = self.wgrad_stream
         if self._repack_event is not None:        # the data-gradient weight copies were refreshed on the side stream (refresh_dgrad_async)
-            torch.cuda.current_stream(self.dev).wait_event(self._repack_event)
+            if side is not None:
+                self.stream_wait(torch.cuda.current_stream(self.dev), side)
             self._repack_event = None
         cuts = {cut: (lo, self.ps.n if hi is None else hi) for cut, lo, hi in self.buckets}
         for i, f in enumerate(self.bwd):
@@ -495,7 +497,15 @@ class Graph(object):
                 self.bucket_done(*cuts[i])
         self.bucket_done(*self.bucket_ranges[-1])
         if side is not None:
-            torch.cuda.current_stream(self.dev).wait_stream(side)
+            self.stream_wait(torch.cuda.current_stream(self.dev), side)
+
+    def stream_wait(self, waiter, signaler):
+        """``waiter`` (a torch stream) waits for everything queued on ``signaler`` so far.  Eager mode goes through the library
+        (yolo_seq_fork) so that the edge becomes part of a recorded launch sequence; under hipGraph capture torch's own event does it"""
+        if self.capturing:
+            waiter.wait_stream(signaler)
+        else:
+            ops.stream_fork(signaler, waiter)
 
     def reduce_slabs(self, lo, hi):
         tab, n, blocks = self.reduce_tables[(lo, hi)]
@@ -547,8 +557,7 @@ class Graph(object):
             self.refresh_dgrad_weights()
             return
         self.on_wgrad_stream(self.refresh_dgrad_weights, flush=True)
-        self._repack_event = torch.cuda.Event()
-        self._repack_event.record(self.wgrad_stream)
+        self._repack_event = True                  # the next backward pass first waits for the side stream (run_backward)
 
     def on_wgrad_stream(self, fn, flush=False, cost=0.0):
         """run fn() on the weight-gradient stream after everything enqueued so far on the current stream.  Hand-offs are BATCHED: an
@@ -575,10 +584,7 @@ class Graph(object):
             for fn in pending:
                 fn()
             return
-        main = torch.cuda.current_stream(self.dev)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
+        self.stream_wait(side, torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
             for fn in pending:
                 fn()

@@ -47,6 +47,10 @@ class YOLOv3Model(object):
         self.overlap_wgrad = True          # weight-gradient GEMMs on a second stream (see engine.Graph.run_backward)
         self.overlap_allreduce = True      # data parallel: each stage's gradient bucket is all-reduced while the earlier layers still run backward
         self.bucket_updates = True         # eager mode: RAdam + L2 per gradient bucket, overlapped with the rest of the backward pass
+        # eager mode: after two plain steps the step's launch list (kernels + cross-stream edges) is recorded once by the native library
+        # and re-issued with one call per step (yolo_seq_run): host cost per step ~2.8 ms of Python + ctypes -> the bare HIP launches
+        self.native_sequencer = True
+        self._seq, self._recording, self._eager_steps = None, None, 0
         self._comm_stream = None
         self._pending = []
         self._step_ranges = []
@@ -110,11 +114,15 @@ class YOLOv3Model(object):
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.stream(s):
-            with torch.cuda.graph(ga, stream=s):
-                self._fwd_bwd()
-            with torch.cuda.graph(gb, stream=s):
-                self._update()
+        self.g.capturing = True
+        try:
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(ga, stream=s):
+                    self._fwd_bwd()
+                with torch.cuda.graph(gb, stream=s):
+                    self._update()
+        finally:
+            self.g.capturing = False
         torch.cuda.current_stream(self.device).wait_stream(s)
         self._graphs = (ga, gb)
 
@@ -139,16 +147,24 @@ class YOLOv3Model(object):
             for t in g.owned_tensors() + [t for t in vars(self.optimizer).values() if isinstance(t, torch.Tensor) and t.is_cuda]:
                 t.record_stream(self._comm_stream)
         cs = self._comm_stream
-        cs.wait_stream(torch.cuda.current_stream(self.device))
+        g.stream_wait(cs, torch.cuda.current_stream(self.device))
         if g.wgrad_stream is not None:
-            cs.wait_stream(g.wgrad_stream)
-        with torch.cuda.stream(cs):
-            work = dist.all_reduce(g.ps.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
-            if then_update:
-                work.wait()                    # the communication stream waits for the collective
+            g.stream_wait(cs, g.wgrad_stream)
+
+        def collective():                      # host work between launches: a segment boundary of a recorded launch sequence
+            with torch.cuda.stream(cs):
+                work = dist.all_reduce(g.ps.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+                if then_update:
+                    work.wait()                # the communication stream waits for the collective
+                else:
+                    self._pending.append(work)
+
+        if self._recording is not None:
+            self._recording.append((ops.seq_mark(), collective))
+        collective()
+        if then_update:
+            with torch.cuda.stream(cs):
                 self.optimizer.launch_range(self, lo, hi, first)
-            else:
-                self._pending.append(work)
 
     def _bucket_ready(self, lo, hi):
         """engine callback (eager mode): the gradient range [lo, hi) is complete behind what is queued on the main and weight-gradient
@@ -174,27 +190,45 @@ class YOLOv3Model(object):
         with torch.cuda.device(self.device):
             if self._graphs is None:
                 g.training = True
+                self._drop_sequence()              # buffers / configuration changed (compile, set_distributed, label slots grew)
+                self._eager_steps = 0
                 self._capture()
             ga, gb = self._graphs
             dp = self.world_size > 1
             if ga is None and self.bucket_updates and (self.overlap_allreduce or not dp):
                 # eager: every gradient bucket is (all-reduced and) updated as soon as it is complete, beside the rest of the backward pass
-                self._step_ranges = []
-                g.on_bucket = self._bucket_ready
+                sig = self._step_signature()
+                if self._seq is not None and self._seq[1] == sig:
+                    self._replay()                                   # the recorded launch list, one native call per segment
+                    return
+                self._drop_sequence()
+                self._eager_steps += 1
+                record = self.native_sequencer and self._eager_steps > 2      # the first steps run plain: one-time set-up happens there
+                if record:
+                    seq_id = ops.seq_begin()
+                    self._recording = []
                 try:
-                    self._fwd_bwd()
+                    self._step_ranges = []
+                    g.on_bucket = self._bucket_ready
+                    try:
+                        self._fwd_bwd()
+                    finally:
+                        g.on_bucket = None
+                    main = torch.cuda.current_stream(self.device)
+                    if self._comm_stream is not None and dp:
+                        g.stream_wait(main, self._comm_stream)
+                    if g.wgrad_stream is not None:
+                        g.stream_wait(main, g.wgrad_stream)
+                    covered = sum(hi - lo for lo, hi in self._step_ranges)
+                    if covered != g.ps.n:
+                        raise RuntimeError('gradient buckets cover %d of %d parameters' % (covered, g.ps.n))
+                    self.optimizer.finish(self)
+                    g.refresh_dgrad_async()
                 finally:
-                    g.on_bucket = None
-                main = torch.cuda.current_stream(self.device)
-                if self._comm_stream is not None and dp:
-                    main.wait_stream(self._comm_stream)
-                if g.wgrad_stream is not None:
-                    main.wait_stream(g.wgrad_stream)
-                covered = sum(hi - lo for lo, hi in self._step_ranges)
-                if covered != g.ps.n:
-                    raise RuntimeError('gradient buckets cover %d of %d parameters' % (covered, g.ps.n))
-                self.optimizer.finish(self)
-                g.refresh_dgrad_async()
+                    if record:
+                        n = ops.seq_end()
+                        segments, self._recording = self._recording, None
+                        self._seq = (seq_id, sig, segments + [(n, None)])
                 return
             if ga is None:
                 self._fwd_bwd()
@@ -209,6 +243,30 @@ class YOLOv3Model(object):
                 self._update()
             else:
                 gb.replay()
+
+    # ---------------------------------------------------------------------------------------------- native launch sequencer
+    def _step_signature(self):
+        """everything a recorded step depends on besides the (static) buffers: a change re-records"""
+        from . import backend
+        g = self.g
+        return (self.overlap_wgrad, self.bucket_updates, self.overlap_allreduce, g.fused_bn_bwd, g.wgrad_batch, g.wgrad_cost_limit, self.world_size,
+                backend.loss_scale(), id(self.loss_obj), id(self.optimizer), int(self.loss_obj.T), g.training, g.bn_momentum,
+                torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _replay(self):
+        seq_id, _, segments = self._seq
+        at = 0
+        for end, host in segments:
+            ops.seq_run(seq_id, at, end)
+            if host is not None:
+                host()
+            at = end
+        self.g._repack_event = True
+
+    def _drop_sequence(self):
+        if self._seq is not None:
+            ops.seq_free(self._seq[0])
+            self._seq = None
 
     def check_device_protocols(self):
         """raise if a bounded device-side wait expired (the single-launch BatchNorm backward's grid barrier): results since the last

@@ -368,3 +368,35 @@ def cast_f32_to_bf16(x, y, n):
 
 def sum_partials(partial, n, add, out):
     check(_lib.load().yolo_sum_partials(_p(partial), n, _p(add), _p(out), _stream()), 'yolo_sum_partials')
+
+
+# ---------------------------------------------------------------------------------------------------------------- launch sequencer
+def stream_fork(from_stream, to_stream):
+    """``to_stream`` waits for everything queued on ``from_stream`` so far (torch streams); recorded when a sequence is being recorded"""
+    check(_lib.load().yolo_seq_fork(C.c_void_p(from_stream.cuda_stream), C.c_void_p(to_stream.cuda_stream)), 'yolo_seq_fork')
+
+
+def seq_begin():
+    r = _lib.load().yolo_seq_begin()
+    if r < 0:
+        check(r, 'yolo_seq_begin')
+    return r
+
+
+def seq_mark():
+    return _lib.load().yolo_seq_mark()
+
+
+def seq_end():
+    r = _lib.load().yolo_seq_end()
+    if r < 0:
+        check(r, 'yolo_seq_end')
+    return r
+
+
+def seq_run(seq, begin, end):
+    check(_lib.load().yolo_seq_run(seq, begin, end), 'yolo_seq_run')
+
+
+def seq_free(seq):
+    check(_lib.load().yolo_seq_free(seq), 'yolo_seq_free')
