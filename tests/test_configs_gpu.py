@@ -146,7 +146,7 @@ def test_native_launch_sequencer_replays_the_step_bit_exactly():
     """after two plain steps the third is recorded by the library (every launch + cross-stream edge of the three-stream schedule) and the
     following ones are re-issued with one native call (yolo_seq_run): 7 steps with the sequencer == 7 steps of plain eager launches, bit for
     bit (the kernels are deterministic); a learning-rate change between steps is honoured (it lives in device memory), and a change of a
-    launch decision drops the recording"""
+    launch decision drops the recording (the step is recorded afresh)"""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from test_train_step_gpu import build, make_batch
@@ -166,9 +166,9 @@ def test_native_launch_sequencer_replays_the_step_bit_exactly():
         if native:
             assert model._seq is not None and len(model._seq[2]) == 1 and model._seq[2][0][0] > 150       # one segment: the whole step
             sid = model._seq[0]
-            model.g.wgrad_batch = 2                      # a launch decision changes: the next step re-records after running plain
+            model.g.wgrad_batch = 2                      # a launch decision changes: the stale recording is dropped, the step re-recorded
             model.train_on_batch(*batches[0])
-            assert model._seq is None
+            assert model._seq is not None and model._seq[0] != sid
         else:
             assert model._seq is None
             model.train_on_batch(*batches[0])
