@@ -57,6 +57,9 @@ CONV_CASES = [
     (2, 10, 10, 256, 128, 1, 1, 'same'),
     (2, 10, 14, 64, 128, 1, 2, 'valid'),    # NIN shortcut
     (2, 16, 16, 8, 64, 3, 2, 'same'),       # stem (RGB padded to 8 channels), K = 72 not a multiple of 64
+    (2, 64, 96, 8, 64, 3, 2, 'same'),       # stem on its row-walking kernel (stem.hip: Wo % 16 == 0), one output row per workgroup
+    (6, 192, 64, 8, 64, 3, 2, 'same'),      # ... two rows per workgroup (N * Ho > 512): the 3-slot input ring rotates, bottom pad row in the last group
+    (1, 32, 608, 8, 64, 3, 2, 'same'),      # ... BASELINE.json configs[4]'s width: > 64 KiB of dynamic LDS
     (1, 7, 7, 512, 256, 3, 1, 'same'),
     (2, 1, 1, 64, 64, 3, 1, 'same'),        # degenerate maps: every tap but the centre is padding
     (3, 2, 5, 64, 128, 3, 1, 'same'),
@@ -142,6 +145,37 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
         torch.testing.assert_close(dx.float().cpu(), xr.grad, rtol=1e-2, atol=1e-2)
         ops.conv2d_dgrad(p, dyd, w_dg, dx, accumulate=True)        # fan-in accumulation: dx += dgrad
         torch.testing.assert_close(dx.float().cpu(), 2 * xr.grad, rtol=2e-2, atol=2e-2)
+
+
+def test_stem_kernel_matches_implicit_gemm(dev):
+    """the row-walking stem kernel against the implicit-GEMM kernel on the same input (yolo_set_tuning 'stem_direct'): same values up to the
+    float32 accumulation order (K is laid out tap-major with 4-channel taps there, 8-channel taps here), statistics rows sum to the same totals"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(9)
+    N, H, W = 5, 224, 160
+    x = bf(torch.rand(N, H, W, 8, generator=g))
+    x[..., 3:] = 0
+    w = bf(torch.randn(64, 3, 3, 8, generator=g) * 0.2)
+    w[..., 3:] = 0
+    p = ops.conv_problem(N, H, W, 8, 64, 3, 2, 'same')
+    outs = []
+    try:
+        for direct in (1, 0):
+            ops.set_tuning('stem_direct', direct)
+            rows = ops.conv2d_stat_rows(p)
+            y = torch.empty(N, p.Ho, p.Wo, 64, dtype=ACT(), device=dev)
+            ss, sq = torch.zeros(rows, 64, device=dev), torch.zeros(rows, 64, device=dev)
+            ops.conv2d_fwd(p, x.to(dev), w.to(dev), y, stat_sum=ss, stat_sq=sq)
+            torch.cuda.synchronize()
+            outs.append((rows, y.float().cpu(), ss.sum(0).cpu(), sq.sum(0).cpu()))
+    finally:
+        ops.set_tuning('stem_direct', 1)
+    (r1, y1, s1, q1), (r0, y0, s0, q0) = outs
+    assert r1 == N * ((p.Ho + 1) // 2) and r1 < r0              # 5 * 112 = 560 > 512 output rows: two per workgroup, one statistics row each
+    torch.testing.assert_close(y1, y0, rtol=2 ** -7, atol=1e-3)
+    assert float((y1 != y0).float().mean()) < 0.02               # only rounding ties of the bf16 store differ
+    torch.testing.assert_close(s1, s0, rtol=1e-3, atol=5e-2)
+    torch.testing.assert_close(q1, q0, rtol=1e-3, atol=5e-2)
 
 
 @pytest.mark.parametrize('bm,bn', [(64, 64), (64, 128), (128, 64), (128, 128), (256, 64), (256, 128)])

@@ -38,6 +38,12 @@ void yolo_set_error(const char* fmt, ...);
     }                                                                                    \
   } while (0)
 
+// ---- dedicated stem convolution (stem.hip), dispatched from yolo_conv2d_fwd / yolo_conv2d_stat_rows ----
+bool yolo_stem_applies(const yolo_conv_problem* p);
+int yolo_stem_stat_rows(const yolo_conv_problem* p);
+int yolo_stem_fwd(const yolo_conv_problem* p, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq, void* stream);
+int yolo_stem_set_direct(int on);
+
 // ---- 16-bit element <-> f32 (round-to-nearest-even; bf16: v_cvt_pk_bf16_f32, fp16: v_cvt_f16_f32 / v_cvt_f32_f16) ----
 #ifdef YOLO_FP16
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }

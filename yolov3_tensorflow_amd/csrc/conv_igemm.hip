@@ -1351,6 +1351,7 @@ extern int g_fused_small_chunks;   // eltwise.hip
 
 extern "C" int yolo_set_tuning(const char* name, int value) {
   YOLO_CHECK_ARG(name != nullptr, "null name");
+  if (!strcmp(name, "stem_direct")) return yolo_stem_set_direct(value);
   if (!strcmp(name, "strip_bm")) { YOLO_CHECK_ARG(value == -1 || value == 0 || value == 64 || value == 128 || value == 256, "strip_bm"); g_strip_bm = value; }
   else if (!strcmp(name, "wgrad_strip")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_strip"); g_wgrad_strip = value; }
   else if (!strcmp(name, "bn_fused_min_chunks")) { YOLO_CHECK_ARG(value >= 1 && value <= 12, "bn_fused_min_chunks"); g_fused_min_chunks = value; }
@@ -1370,6 +1371,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
 extern "C" int yolo_conv2d_stat_rows(const yolo_conv_problem* p) {
   if (!p || p->Cout % 64 != 0 || p->N <= 0 || p->Ho <= 0 || p->Wo <= 0) return YOLO_ERR_INVALID_ARG;
   if (check_problem(p)) return YOLO_ERR_INVALID_ARG;
+  if (yolo_stem_applies(p)) return yolo_stem_stat_rows(p);
   static const char dummy = 0;
   return stat_rows_for(fwd_gather(p, &dummy, &dummy), p->Cout);
 }
@@ -1382,6 +1384,7 @@ extern "C" int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, con
   YOLO_CHECK_ARG(p->C0 == 0 || src0, "C0 > 0 needs src0");
   YOLO_CHECK_ARG((stat_sum == nullptr) == (stat_sq == nullptr), "stat_sum and stat_sq go together");
   YOLO_CHECK_ARG(!(y_is_f32 && stat_sum), "statistics are defined on bf16 outputs only");
+  if (!y_is_f32 && !bias && yolo_stem_applies(p)) return yolo_stem_fwd(p, src1, w_fwd, y, stat_sum, stat_sq, stream);   // RGB stem: row-walking kernel
   Gather g = fwd_gather(p, src0, src1);
   if (y_is_f32) return launch_fwd<true>(g, w_fwd, bias, y, p->Cout, 0, nullptr, nullptr, p->Cout, (hipStream_t)stream);
   return launch_fwd<false>(g, w_fwd, bias, y, p->Cout, 0, stat_sum, stat_sq, p->Cout, (hipStream_t)stream);
