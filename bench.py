@@ -118,7 +118,7 @@ def kernel_rooflines(model, steps, overlap):
 
     n_params = model.g.ps.n
     patched = {'conv2d_fwd': timed_conv(ops.conv2d_fwd), 'conv2d_dgrad': timed_conv(ops.conv2d_dgrad)}
-    for name in ('bn_act_fwd', 'bn_pool_fwd', 'bn_finalize_act_fwd'):
+    for name in ('bn_act_fwd', 'bn_pool_fwd'):
         patched[name] = timed_bytes(getattr(ops, name), 'bn_fwd')
     for name in ('bn_act_bwd_fused', 'bn_act_bwd_reduce', 'bn_act_bwd_apply', 'bn_pool_bwd_reduce', 'bn_pool_bwd_apply'):
         patched[name] = timed_bytes(getattr(ops, name), 'bn_bwd')
@@ -249,7 +249,6 @@ def main():
     ap.add_argument('--side-priority', type=int, default=None, help='priority of the weight-gradient stream (A/B probe)')
     ap.add_argument('--no-sequencer', action='store_true', help='enqueue every launch from Python instead of replaying the recorded launch list')
     ap.add_argument('--no-bucket-updates', action='store_true', help='one RAdam + L2 launch after the backward pass instead of one per gradient bucket')
-    ap.add_argument('--no-fused-bn-fwd', action='store_true', help='separate bn_finalize + bn_act_fwd launches on the small maps too')
     ap.add_argument('--no-fused-bn', action='store_true', help='three-kernel BatchNorm backward instead of the single-launch one')
     args = ap.parse_args()
 
@@ -278,7 +277,6 @@ def main():
     model.use_hip_graph = bool(args.graph)
     model.overlap_wgrad = not args.no_overlap
     model.g.fused_bn_bwd = not args.no_fused_bn
-    model.g.fused_bn_fwd = not args.no_fused_bn_fwd
     model.bucket_updates = not args.no_bucket_updates
     model.native_sequencer = not args.no_sequencer
     if args.side_priority is not None:

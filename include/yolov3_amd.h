@@ -146,18 +146,6 @@ int yolo_bn_bwd_finalize_grouped(const float* partial, int P, int64_t row_stride
 /* out = act(y*scale + shift + T); T = 0 (res NULL), res (res_scale NULL) or res*res_scale + res_shift; scale NULL = identity */
 int yolo_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
                     const float* res_shift, void* out, int64_t M, int C, int relu, void* stream);
-/* yolo_bn_finalize (of up to two BatchNorms: the main branch and a conv shortcut) and yolo_bn_act_fwd in ONE launch, for the small maps
- * where both are launch latency (P <= 384 partial rows, C % 64 == 0): every workgroup reduces the partial rows of its own 64 channels and
- * applies; scale / shift / mean / rstd are published and the moving statistics updated once.  res_bn NULL: res (if any) is added as is. */
-typedef struct yolo_bn_fwd_source {
-  const float* psum; const float* psq;   /* [P][row stride] partial sums / sums of squares (conv epilogue) */
-  int32_t P; int64_t rstride;
-  const float* gamma; const float* beta; /* NULL = 1 / 0 */
-  float* moving_mean; float* moving_var; /* NULL = not updated */
-  float* scale; float* shift; float* mean; float* rstd;   /* outputs [C] */
-} yolo_bn_fwd_source;
-int yolo_bn_finalize_act_fwd(const yolo_bn_fwd_source* main_bn, const yolo_bn_fwd_source* res_bn, float count, float eps, float momentum,
-                             const void* y, const void* res, void* out, int64_t M, int C, int relu, void* stream);
 /* out[N,Ho,Wo,C] = act(maxpool3x3s2(y*scale + shift)); argmax[N,Ho,Wo,C] = window position 0..8 of the first maximum */
 int yolo_bn_pool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax, int N, int H, int W, int C,
                      int Ho, int Wo, int pad_t, int pad_l, int relu, void* stream);

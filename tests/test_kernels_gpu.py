@@ -147,63 +147,6 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
         torch.testing.assert_close(dx.float().cpu(), 2 * xr.grad, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize('C,M,P,two,res,relu', [(512, 5408, 85, False, False, True), (256, 21632, 169, True, True, True), (64, 700, 384, False, True, False),
-                                                    (128, 1000, 3, True, True, True)])
-def test_bn_finalize_act_fwd_matches_the_two_launches(dev, C, M, P, two, res, relu):
-    """the one-launch BatchNorm finalize + apply of the small maps against yolo_bn_finalize + yolo_bn_act_fwd on the same partial rows: the same
-    scale / shift / mean / rstd / moving statistics up to the summation order of the rows (1e-6), outputs equal up to one bf16 rounding"""
-    from yolov3_tensorflow_amd import ops
-    g = torch.Generator().manual_seed(C + P)
-    y = bf(torch.randn(M, C, generator=g) * 1.5 + 0.3).to(dev)
-    r = bf(torch.randn(M, C, generator=g)).to(dev) if res else None
-
-    def partial_rows(t):                                   # P partial rows whose column sums are the tensor's sums (as a conv epilogue leaves them)
-        rows = torch.tensor_split(t.float(), P, dim=0)
-        return torch.stack([x.sum(0) for x in rows]).contiguous(), torch.stack([(x * x).sum(0) for x in rows]).contiguous()
-
-    def bn_buffers():
-        return dict(gamma=(torch.rand(C, generator=g) + 0.5).to(dev), beta=torch.randn(C, generator=g).to(dev), mm=torch.randn(C, generator=g).to(dev),
-                    mv=(torch.rand(C, generator=g) + 0.5).to(dev))
-
-    ps, pq = partial_rows(y)
-    b1 = bn_buffers()
-    b2 = bn_buffers() if two else None
-    if two:
-        ps2, pq2 = partial_rows(r)
-    outs = []
-    for fused in (False, True):
-        o = torch.empty(M, C, dtype=ACT(), device=dev)
-        w1 = [torch.empty(C, device=dev) for _ in range(4)]
-        w2 = [torch.empty(C, device=dev) for _ in range(4)]
-        mm1, mv1 = b1['mm'].clone(), b1['mv'].clone()
-        mm2, mv2 = (b2['mm'].clone(), b2['mv'].clone()) if two else (None, None)
-        if fused:
-            s1 = ops.bn_fwd_source(ps, pq, P, C, b1['gamma'], b1['beta'], mm1, mv1, *w1)
-            s2 = ops.bn_fwd_source(ps2, pq2, P, C, b2['gamma'], b2['beta'], mm2, mv2, *w2) if two else None
-            ops.bn_finalize_act_fwd(s1, s2, M, 1e-5, 0.9, y, o, M, C, relu, res=r)
-        else:
-            ops.bn_finalize(ps.view(-1), pq.view(-1), P, C, C, M, b1['gamma'], b1['beta'], 1e-5, 0.9, mm1, mv1, *w1)
-            if two:
-                ops.bn_finalize(ps2.view(-1), pq2.view(-1), P, C, C, M, b2['gamma'], b2['beta'], 1e-5, 0.9, mm2, mv2, *w2)
-            ops.bn_act_fwd(y, w1[0], w1[1], o, M, C, relu, res=r, res_scale=w2[0] if two else None, res_shift=w2[1] if two else None)
-        torch.cuda.synchronize()
-        outs.append((o.float().cpu(), [t.cpu() for t in w1 + [mm1, mv1]], [t.cpu() for t in w2 + [mm2, mv2]] if two else []))
-    (o0, a0, c0), (o1, a1, c1) = outs
-    for x0, x1 in zip(a0 + c0, a1 + c1):
-        torch.testing.assert_close(x1, x0, rtol=2e-6, atol=2e-6)
-    assert float((o1 - o0).abs().max()) <= 2 ** -7 * float(o0.abs().max())
-    assert float((o1 != o0).float().mean()) < 1e-3
-    # against float32 torch on the same inputs
-    yf = y.float().cpu()
-    ref = (yf - yf.mean(0)) / torch.sqrt(yf.var(0, unbiased=False) + 1e-5) * b1['gamma'].cpu() + b1['beta'].cpu()
-    if res:
-        rf = r.float().cpu()
-        ref = ref + ((rf - rf.mean(0)) / torch.sqrt(rf.var(0, unbiased=False) + 1e-5) * b2['gamma'].cpu() + b2['beta'].cpu() if two else rf)
-    if relu:
-        ref = torch.relu(ref)
-    torch.testing.assert_close(o1, ref, rtol=2e-2, atol=2e-2)
-
-
 def test_stem_kernel_matches_implicit_gemm(dev):
     """the row-walking stem kernel against the implicit-GEMM kernel on the same input (yolo_set_tuning 'stem_direct'): same values up to the
     float32 accumulation order (K is laid out tap-major with 4-channel taps there, 8-channel taps here), statistics rows sum to the same totals"""

@@ -39,12 +39,6 @@ class ImageDesc(C.Structure):
                 ('reserved', C.c_int32)]
 
 
-class BnFwdSource(C.Structure):
-    _fields_ = [('psum', C.c_void_p), ('psq', C.c_void_p), ('P', C.c_int32), ('rstride', C.c_int64), ('gamma', C.c_void_p), ('beta', C.c_void_p),
-                ('moving_mean', C.c_void_p), ('moving_var', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p),
-                ('rstd', C.c_void_p)]
-
-
 P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 CP = C.POINTER(ConvProblem)
 MP = C.POINTER(MixProblem)
@@ -80,7 +74,6 @@ SIGNATURES = {
     'yolo_bn_finalize_grouped': (I, [P, P, I, C.c_int64, I, C.c_float, I, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P]),
     'yolo_bn_bwd_finalize_grouped': (I, [P, I, C.c_int64, C.c_int64, I, I, C.c_float, I, P, P, P, P, P, P]),
     'yolo_bn_act_fwd': (I, [P, P, P, P, P, P, P, I64, I, I, P]),
-    'yolo_bn_finalize_act_fwd': (I, [C.POINTER(BnFwdSource), C.POINTER(BnFwdSource), F, F, F, P, P, P, I64, I, I, P]),
     'yolo_bn_pool_fwd': (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     'yolo_bn_act_bwd_reduce': (I, [P, P, I, P, P, P, P, P, P, I, I, P, P]),
     'yolo_bn_bwd_finalize': (I, [P, I, I64, I64, I, I, F, P, P, P, P, P]),

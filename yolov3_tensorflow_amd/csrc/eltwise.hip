@@ -236,103 +236,6 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __
   }
 }
 
-// ---- small maps: BatchNorm finalize + apply in ONE launch ----
-// On the 13 x 13 / 26 x 26 maps the tensor is a few MB: bn_finalize (6.5 us) and bn_act_fwd (5-10 us) are both pure launch latency, and the
-// forward pass is one serial chain of such launches.  Here a workgroup owns 64 channels x a pixel range: it first reduces the conv
-// epilogue's partial statistics rows for ITS 64 channels (P rows x 64 x 2 floats from L2: P <= 384 keeps that under 200 KB; every workgroup
-// of a channel slice repeats the same sums in the same order, so they all hold bit-identical scale / shift), then applies.  The workgroups
-// of pixel range 0 also publish scale / shift / mean / rstd (the backward pass reads them) and update the moving statistics.
-struct BnFwdSrc {
-  const float* psum; const float* psq; int P; long long rstride;      // psum == nullptr: this BatchNorm is absent
-  const float* gamma; const float* beta; float* moving_mean; float* moving_var;
-  float* scale; float* shift; float* mean; float* rstd;
-};
-
-__device__ __forceinline__ void bn_small_finalize(const BnFwdSrc& b, int c0, float count, float eps, float momentum, bool publish,
-                                                  double (*red)[4][64], float* s_scale, float* s_shift) {
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;              // 256 threads: 64 channels x 4 row lanes
-  float f[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  int p = rl;
-  for (; p + 12 < b.P; p += 16) {                                       // 4 loads per quantity in flight
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      f[0][u] += b.psum[(size_t)(p + 4 * u) * b.rstride + c0 + cl];
-      f[1][u] += b.psq[(size_t)(p + 4 * u) * b.rstride + c0 + cl];
-    }
-  }
-  for (; p < b.P; p += 4) {
-    f[0][0] += b.psum[(size_t)p * b.rstride + c0 + cl];
-    f[1][0] += b.psq[(size_t)p * b.rstride + c0 + cl];
-  }
-  red[0][rl][cl] = ((double)f[0][0] + (double)f[0][1]) + ((double)f[0][2] + (double)f[0][3]);
-  red[1][rl][cl] = ((double)f[1][0] + (double)f[1][1]) + ((double)f[1][2] + (double)f[1][3]);
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int c = c0 + cl;
-    const double ts = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-    const double tq = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
-    const double mean = ts / (double)count;
-    double var = tq / (double)count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = b.gamma ? b.gamma[c] : 1.f, be = b.beta ? b.beta[c] : 0.f;
-    const float sc = g * rstd, sh = be - (float)mean * sc;
-    s_scale[cl] = sc;
-    s_shift[cl] = sh;
-    if (publish) {
-      b.scale[c] = sc; b.shift[c] = sh; b.mean[c] = (float)mean; b.rstd[c] = rstd;
-      if (b.moving_mean) {
-        const double unb = count > 1.f ? var * ((double)count / ((double)count - 1.0)) : var;
-        b.moving_mean[c] = momentum * b.moving_mean[c] + (1.f - momentum) * (float)mean;
-        b.moving_var[c] = momentum * b.moving_var[c] + (1.f - momentum) * (float)unb;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_act_fwd_kernel(BnFwdSrc a, BnFwdSrc b, float count, float eps, float momentum,
-                                                                  const bf16_t* __restrict__ y, const bf16_t* __restrict__ res,
-                                                                  bf16_t* __restrict__ out, int M, int C, int relu, int ppw) {
-  __shared__ double red[2][4][64];
-  __shared__ float s_sc[2][64], s_sh[2][64];
-  const int c0 = blockIdx.y * 64;
-  const bool publish = blockIdx.x == 0;
-  bn_small_finalize(a, c0, count, eps, momentum, publish, red, s_sc[0], s_sh[0]);
-  const bool two = b.psum != nullptr;
-  if (two) bn_small_finalize(b, c0, count, eps, momentum, publish, red, s_sc[1], s_sh[1]);
-  const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;               // 8 chunks of 8 channels x 32 pixels per trip
-  float sc[8], sh[8], sc2[8], sh2[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sc[j] = s_sc[0][ch * 8 + j]; sh[j] = s_sh[0][ch * 8 + j];
-    sc2[j] = two ? s_sc[1][ch * 8 + j] : 1.f; sh2[j] = two ? s_sh[1][ch * 8 + j] : 0.f;
-  }
-  const int m0 = blockIdx.x * ppw, m1 = min(m0 + ppw, M);
-  for (int m = m0 + pl; m < m1; m += 32) {
-    const size_t off = (size_t)m * C + c0 + ch * 8;
-    float v[8];
-    unpack_bf8(ld16(y + off), v);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
-    if (res) {
-      float r[8];
-      unpack_bf8(ld16(res + off), r);
-      if (two) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = r[j] * sc2[j] + sh2[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += r[j];
-    }
-    if (relu) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-    }
-    st16(out + off, pack_bf8(v));
-  }
-}
-
 // ---- stem: out = act(maxpool3x3s2(y * scale + shift)), argmax (0..8, first maximum in row-major window order) ----
 __global__ __launch_bounds__(EW_THREADS) void bn_pool_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, bf16_t* __restrict__ out,
@@ -1185,33 +1088,6 @@ extern "C" int yolo_bn_act_fwd(const void* y, const float* scale, const float* s
   const size_t nch = (size_t)M * (C / 8);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, scale, shift,
                      (const bf16_t*)res, res_scale, res_shift, (bf16_t*)out, nch, C, relu);
-  YOLO_LAUNCH_CHECK();
-  return YOLO_OK;
-}
-
-extern "C" int yolo_bn_finalize_act_fwd(const yolo_bn_fwd_source* main_bn, const yolo_bn_fwd_source* res_bn, float count, float eps, float momentum,
-                                        const void* y, const void* res, void* out, int64_t M, int C, int relu, void* stream) {
-  YOLO_CHECK_ARG(main_bn && main_bn->psum && main_bn->psq && y && out && M > 0 && M < (1ll << 31) && C > 0 && C % 64 == 0 && count > 0.f, "bad argument");
-  YOLO_CHECK_ARG(main_bn->scale && main_bn->shift && main_bn->mean && main_bn->rstd && main_bn->P > 0 && main_bn->P <= 384 && main_bn->rstride >= C,
-                 "main BatchNorm: outputs / P in 1..384 / row stride");
-  YOLO_CHECK_ARG(!res_bn || (res && res_bn->psum && res_bn->psq && res_bn->scale && res_bn->shift && res_bn->mean && res_bn->rstd && res_bn->P > 0 &&
-                             res_bn->P <= 384 && res_bn->rstride >= C), "shortcut BatchNorm: needs res, outputs, P in 1..384");
-  auto conv = [](const yolo_bn_fwd_source* s) {
-    BnFwdSrc o = {};
-    if (s) {
-      o.psum = s->psum; o.psq = s->psq; o.P = s->P; o.rstride = s->rstride; o.gamma = s->gamma; o.beta = s->beta;
-      o.moving_mean = s->moving_mean; o.moving_var = s->moving_var; o.scale = s->scale; o.shift = s->shift; o.mean = s->mean; o.rstd = s->rstd;
-    }
-    return o;
-  };
-  const int slices = C / 64;
-  int groups = 512 / slices;                        // ~512 workgroups of 256 threads
-  if (groups < 1) groups = 1;
-  int ppw = (int)((M + groups - 1) / groups);
-  ppw = (ppw + 31) / 32 * 32;                       // whole 32-pixel trips
-  groups = (int)((M + ppw - 1) / ppw);
-  hipLaunchKernelGGL(bn_finalize_act_fwd_kernel, dim3(groups, slices), dim3(256), 0, (hipStream_t)stream, conv(main_bn), conv(res_bn), count, eps,
-                     momentum, (const bf16_t*)y, (const bf16_t*)res, (bf16_t*)out, (int)M, C, relu, ppw);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

@@ -185,7 +185,6 @@ class Graph(object):
         self.tape = []
         self._repack_event = None
         self.fused_bn_bwd = True         # single-launch BatchNorm backward where the tensor fits (ops.bn_act_bwd_fused)
-        self.fused_bn_fwd = True         # small maps: BatchNorm finalize + apply in one launch (ops.bn_finalize_act_fwd)
         self.vals = []
         self.bns = []            # every keras BatchNormalization (for checkpoints)
         self.bn_groups = []      # allocation units: a BNState or a MultiBN
@@ -731,7 +730,6 @@ class ApplyOp(object):
         self.g, self.out, self.relu = g, out, relu
         self.m_src, self.m_bn = _branch(main)
         self.o_src, self.o_bn = (None, None) if other is None else _branch(other)
-        self._fused = None
         if self.o_src is not None and self.o_bn is None and self.o_src.kind == 'conv':
             raise NotImplementedError('raw conv output as the secondary sum operand')
 
@@ -758,27 +756,7 @@ class ApplyOp(object):
             psum, psq, P, rs = flat, flat[self.C:], self.P, 2 * self.C
         bn.fwd_finalize(psum, psq, P, rs, self.M, self.g.training)
 
-    def _fused_fwd_source(self, src, bn):
-        """the BatchNorm as an argument of the one-launch finalize + apply (small maps), or None if it has to go through bn_finalize"""
-        if bn is None or len(bn.parts) != 1 or src.kind != 'conv' or not hasattr(src, 'stats') or self.C % 64:
-            return None
-        psum, psq, P, rs = src.stats
-        if P > ops.BN_FUSED_FWD_MAX_ROWS or rs < self.C:
-            return None
-        b = bn.parts[0][0]
-        return ops.bn_fwd_source(psum, psq, P, rs, b.v_gamma, b.v_beta, b.moving_mean, b.moving_var, b.scale, b.shift, b.mean, b.rstd)
-
     def forward(self):
-        g = self.g
-        if g.training and g.fused_bn_fwd:
-            if self._fused is None:                # (decided once: the operands are static)
-                main = self._fused_fwd_source(self.m_src, self.m_bn)
-                other = self._fused_fwd_source(self.o_src, self.o_bn) if self.o_bn is not None else None
-                self._fused = (main, other) if main is not None and (self.o_bn is None or other is not None) else False
-            if self._fused:
-                ops.bn_finalize_act_fwd(self._fused[0], self._fused[1], self.M, BN_EPSILON, g.bn_momentum, self.m_src.buf, self.out.buf, self.M,
-                                        self.C, self.relu, res=None if self.o_src is None else self.o_src.buf)
-                return
         if self.m_bn is not None:
             self._finalize_bn(self.m_src, self.m_bn)
         if self.o_bn is not None:

@@ -249,7 +249,7 @@ class YOLOv3Model(object):
         """everything a recorded step depends on besides the (static) buffers: a change re-records"""
         from . import backend
         g = self.g
-        return (self.overlap_wgrad, self.bucket_updates, self.overlap_allreduce, g.fused_bn_bwd, g.fused_bn_fwd, g.wgrad_batch, g.wgrad_cost_limit, self.world_size,
+        return (self.overlap_wgrad, self.bucket_updates, self.overlap_allreduce, g.fused_bn_bwd, g.wgrad_batch, g.wgrad_cost_limit, self.world_size,
                 backend.loss_scale(), id(self.loss_obj), id(self.optimizer), int(self.loss_obj.T), g.training, g.bn_momentum,
                 torch.cuda.current_stream(self.device).cuda_stream)
 

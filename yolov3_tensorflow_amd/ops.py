@@ -150,20 +150,6 @@ def bn_act_fwd(y, scale, shift, out, M, Cc, relu, res=None, res_scale=None, res_
                                       _stream()), 'yolo_bn_act_fwd')
 
 
-def bn_fwd_source(psum, psq, P, row_stride, gamma, beta, moving_mean, moving_var, scale, shift, mean, rstd):
-    d = lambda t: None if t is None else t.data_ptr()
-    return _lib.BnFwdSource(d(psum), d(psq), P, row_stride, d(gamma), d(beta), d(moving_mean), d(moving_var), d(scale), d(shift), d(mean), d(rstd))
-
-
-BN_FUSED_FWD_MAX_ROWS = 384
-
-
-def bn_finalize_act_fwd(main_bn, res_bn, count, eps, momentum, y, out, M, Cc, relu, res=None):
-    """bn_finalize (main + optional shortcut BatchNorm) and bn_act_fwd in one launch (small maps: P <= 384 partial rows, C % 64 == 0)"""
-    check(_lib.load().yolo_bn_finalize_act_fwd(C.byref(main_bn), None if res_bn is None else C.byref(res_bn), float(count), eps, momentum, _p(y),
-                                               _p(res), _p(out), M, Cc, int(relu), _stream()), 'yolo_bn_finalize_act_fwd')
-
-
 def bn_pool_fwd(y, scale, shift, out, argmax, N, H, W, Cc, Ho, Wo, pt, pl, relu):
     check(_lib.load().yolo_bn_pool_fwd(_p(y), _p(scale), _p(shift), _p(out), _p(argmax), N, H, W, Cc, Ho, Wo, pt, pl, int(relu),
                                        _stream()), 'yolo_bn_pool_fwd')
