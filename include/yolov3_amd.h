@@ -180,6 +180,9 @@ int yolo_bn_act_bwd_fused_grouped(const void* dout, const void* out, int relu, i
                                   const float* rstd2, float* dgamma2, float* dbeta2, void* dy2, void* dres, int acc_dres,
                                   float* workspace, int* sync_words, void* stream);
 int yolo_bn_fused_timeouts(const int* sync_words, int* host_out);
+/* Register a HOST-visible word (pinned, device-accessible memory; NULL removes it): a grid-barrier time-out additionally stores 1 there with
+ * system scope, so the owner can refuse to enqueue the next step without synchronising the device first. */
+int yolo_bn_fused_set_host_flag(int* sync_words, int* host_flag);
 /* the same two passes through the stem's max-pool (rows = pre-pool pixels N*H*W) */
 /* (with relu and non-NULL gamma/beta the sums are taken over the pooled map: xhat = (out - beta) / gamma, y/argmax are not read) */
 int yolo_bn_pool_bwd_reduce(const void* dout, const void* out, const uint8_t* argmax, int relu, const void* y, const float* mean,

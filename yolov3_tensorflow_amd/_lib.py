@@ -83,6 +83,7 @@ SIGNATURES = {
     'yolo_bn_act_bwd_fused': (I, [P, P, I, C.c_int64, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P, P, P]),
     'yolo_bn_act_bwd_fused_grouped': (I, [P, P, I, C.c_int64, I, P, P, P, P, I, P, P, P, P, I, P, P, P, P, P, P, P, P, I, P, P, P]),
     'yolo_bn_fused_timeouts': (I, [P, P]),
+    'yolo_bn_fused_set_host_flag': (I, [P, P]),
     'yolo_bn_pool_bwd_reduce': (I, [P, P, P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, P]),
     'yolo_bn_pool_bwd_apply': (I, [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     'yolo_upcat_split_bwd': (I, [P, P, I, P, I, I, I, I, I, I, P]),

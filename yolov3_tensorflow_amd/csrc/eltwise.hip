@@ -723,7 +723,16 @@ __device__ __forceinline__ void grid_arrive_wait(int* sync) {
     if (nl) ok = (int)((unsigned)__hip_atomic_load(sync + lane * FB_SHARD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
     if (__all(ok)) break;
     __builtin_amdgcn_s_sleep(4);
-    if (++spins > FB_SPIN_LIMIT) { if (lane == 0) atomicAdd(sync + FB_TIMEOUT_WORD, 1); break; }
+    if (++spins > FB_SPIN_LIMIT) {
+      if (lane == 0) {
+        atomicAdd(sync + FB_TIMEOUT_WORD, 1);
+        // a host-visible (pinned) word, if the owner registered one (yolo_bn_fused_set_host_flag): the host sees the failure before it
+        // enqueues the next step, without synchronising the device
+        int* host_flag = *reinterpret_cast<int* const*>(sync + FB_TIMEOUT_WORD + 2);
+        if (host_flag) __hip_atomic_store(host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      break;
+    }
   }
 }
 
@@ -1157,6 +1166,15 @@ extern "C" int yolo_bn_fused_timeouts(const int* sync_words, int* host_out) {
   if (e == hipSuccess) e = hipMemcpy(&t[1], sync_words + FB_SYNC_WORDS + FB_TIMEOUT_WORD, sizeof(int), hipMemcpyDeviceToHost);
   if (e != hipSuccess) { yolo_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); return (int)e; }
   *host_out = t[0] + t[1];
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_fused_set_host_flag(int* sync_words, int* host_flag) {
+  YOLO_CHECK_ARG(sync_words, "null pointer");
+  for (int set = 0; set < 2; ++set) {                 // the full grid's and the small grid's counter sets
+    hipError_t e = hipMemcpy(sync_words + set * FB_SYNC_WORDS + FB_TIMEOUT_WORD + 2, &host_flag, sizeof(host_flag), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { yolo_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); return (int)e; }
+  }
   return YOLO_OK;
 }
 

@@ -32,6 +32,15 @@ class YOLOv3Model(object):
             heads = detector._detection_head(detector.backbone.build(x), self.head_channel_nums, self.head_names)
             g.finalize(heads)
             g.refresh_dgrad_weights()
+            # a time-out of the single-launch BatchNorm backward's grid barrier (its cooperative grid was not resident) raises this pinned
+            # word; run_step looks at it before it enqueues anything: the failure is loud at the very next step, not at the epoch's end
+            self._bn_flag = torch.zeros(1, dtype=torch.int32)
+            try:
+                self._bn_flag = self._bn_flag.pin_memory()
+            except RuntimeError:                           # no device behind torch.cuda (the CPU suite builds graphs with mocked kernels)
+                pass
+            if self._bn_flag.is_pinned():
+                ops.bn_fused_set_host_flag(g.bn_sync, self._bn_flag)
         self.g = g
         self.heads = heads                       # engine.Val (kind 'conv', float32, channel-padded), order /8, /16, /32
         self.ldc = [h.shape[3] for h in heads]
@@ -187,6 +196,9 @@ class YOLOv3Model(object):
         if self.loss_obj is None or self.optimizer is None:
             raise RuntimeError('compile(optimizer, loss) first')
         g = self.g
+        if int(self._bn_flag[0]) != 0:
+            raise RuntimeError('a grid barrier of yolo_bn_act_bwd_fused timed out in an earlier step (its cooperative grid was not resident: '
+                               'another process on the GPU?): results since then are invalid; rerun with g.fused_bn_bwd = False')
         with torch.cuda.device(self.device):
             if self._graphs is None:
                 g.training = True

@@ -209,6 +209,11 @@ def bn_fused_timeouts(sync):
     return n.value
 
 
+def bn_fused_set_host_flag(sync, host_flag):
+    """host_flag: a pinned int32 tensor (or None): set to 1 by the kernel when its grid barrier times out"""
+    check(_lib.load().yolo_bn_fused_set_host_flag(_p(sync), _p(host_flag)), 'yolo_bn_fused_set_host_flag')
+
+
 def bn_pool_bwd_reduce(dout, out, argmax, relu, y, mean, rstd, N, H, W, Cc, Ho, Wo, pt, pl, partial, gamma=None, beta=None):
     check(_lib.load().yolo_bn_pool_bwd_reduce(_p(dout), _p(out), _p(argmax), int(relu), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta),
                                               N, H, W, Cc, Ho, Wo, pt, pl, _p(partial), _stream()), 'yolo_bn_pool_bwd_reduce')
