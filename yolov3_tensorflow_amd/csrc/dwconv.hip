@@ -19,6 +19,9 @@ struct MixP {
 };
 
 constexpr int DW_THREADS = 256;
+#ifndef DW_MIN_WAVES
+#define DW_MIN_WAVES 2
+#endif
 
 __device__ __forceinline__ uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
@@ -133,7 +136,7 @@ __device__ __forceinline__ void dw_tile(const MixP& p, const bf16_t* __restrict_
   }
 }
 
-__global__ __launch_bounds__(DW_THREADS) void dwconv_mix_kernel(MixP p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w0,
+__global__ __launch_bounds__(DW_THREADS, DW_MIN_WAVES) void dwconv_mix_kernel(MixP p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w0,
                                                                 const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
                                                                 const bf16_t* __restrict__ w3, bf16_t* __restrict__ y, int flip, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) uint4 dw_smem[];
@@ -223,7 +226,7 @@ __device__ __forceinline__ void dw_wgrad_tile(const MixP& p, const bf16_t* __res
   }
 }
 
-__global__ __launch_bounds__(DW_THREADS) void dwconv_mix_wgrad_kernel(MixP p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(DW_THREADS, DW_MIN_WAVES) void dwconv_mix_wgrad_kernel(MixP p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                       float* __restrict__ s0, float* __restrict__ s1, float* __restrict__ s2,
                                                                       float* __restrict__ s3) {
   extern __shared__ __attribute__((aligned(16))) uint4 dw_smem[];
