@@ -79,6 +79,8 @@ int yolo_conv2d_stat_rows(const yolo_conv_problem* p);
 /* Test / benchmark hook: override a kernel-selection heuristic.  "strip_bm": -1 auto (default), 0 never use the LDS-resident strip
  * kernel for 3x3 stride-1 convolutions, 64 / 128 / 256 force its pixel tile; "strip_bn": 0 auto, 64 / 128; "wgrad_strip": 0 / 1;
  * "stem_direct": 1 (default) / 0 the RGB stem (Cin 8, Cout 64, 3x3 stride 2) on its row-walking kernel or on the implicit GEMM (changes yolo_conv2d_stat_rows);
+ * "dw_tiled": 1 (default) / 0 the mixed depthwise forward / data gradient on its tiled kernel or on the row-tile kernel, > 1 = workgroups per
+ * 64-channel slab of the tiled kernel's persistent grid (default 512);
  * "strip_ws": 0 auto / 2 / 3 weight-ring stages; "s2_classes": 0 / 1 stride-2 data gradient as four dense parity classes;
  * "wgrad_target": workgroups the split-K plan aims at (64..4096, default 384; changes yolo_conv2d_wgrad_workspace_bytes);
  * "wgrad_xcd": 0 / 1 XCD-chunked 1-D weight-gradient grids; "wgrad_ring": 2 / 3 operand stages and "wgrad_pipe": 0 / 1 software-pipelined

@@ -43,6 +43,7 @@ bool yolo_stem_applies(const yolo_conv_problem* p);
 int yolo_stem_stat_rows(const yolo_conv_problem* p);
 int yolo_stem_fwd(const yolo_conv_problem* p, const void* x, const void* w, void* y, float* stat_sum, float* stat_sq, void* stream);
 int yolo_stem_set_direct(int on);
+int yolo_dw_set_tiled(int on);       // dwconv.hip
 
 // ---- 16-bit element <-> f32 (round-to-nearest-even; bf16: v_cvt_pk_bf16_f32, fp16: v_cvt_f16_f32 / v_cvt_f32_f16) ----
 #ifdef YOLO_FP16

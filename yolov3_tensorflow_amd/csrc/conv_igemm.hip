@@ -1352,6 +1352,7 @@ extern int g_fused_small_chunks;   // eltwise.hip
 extern "C" int yolo_set_tuning(const char* name, int value) {
   YOLO_CHECK_ARG(name != nullptr, "null name");
   if (!strcmp(name, "stem_direct")) return yolo_stem_set_direct(value);
+  if (!strcmp(name, "dw_tiled")) return yolo_dw_set_tiled(value);
   if (!strcmp(name, "strip_bm")) { YOLO_CHECK_ARG(value == -1 || value == 0 || value == 64 || value == 128 || value == 256, "strip_bm"); g_strip_bm = value; }
   else if (!strcmp(name, "wgrad_strip")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_strip"); g_wgrad_strip = value; }
   else if (!strcmp(name, "bn_fused_min_chunks")) { YOLO_CHECK_ARG(value >= 1 && value <= 12, "bn_fused_min_chunks"); g_fused_min_chunks = value; }

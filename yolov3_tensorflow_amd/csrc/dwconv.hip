@@ -153,6 +153,195 @@ __global__ __launch_bounds__(DW_THREADS, DW_MIN_WAVES) void dwconv_mix_kernel(Mi
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Tiled forward / data gradient (the default).  The row-tile kernel above gives every workgroup ONE 8-channel chunk of wide maps (16-byte
+// accesses at a 128-byte stride), the same 256 workgroups to every kernel size although k = 9 carries 9x the work per channel of k = 3, and
+// compiles all sizes into one register budget (256 VGPRs: one wave per SIMD): 100 us on the 104 x 104 x 64 map against ~20 us of HBM time.
+// Here a workgroup owns an 8 x 16 output tile of one image for a SLAB of 64 consecutive channels (all kernel sizes that fall into it):
+//   * the halo'd input tile is staged as whole 128-byte pixels (coalesced), zero outside the image; the slab's weights are staged as
+//     float32 (flipped for the data gradient), so lanes read them with broadcast LDS reads instead of unpacking them again and again
+//   * work is handed out per WAVE: a wave-task is up to 64 lanes of ONE kernel size -- lane = (chunk, row, strip of SP pixels), SP = 8 / 4 / 2
+//     for k = 3 / 5 / 7,9, so that every kernel size fills a wave -- and the tasks are dealt to the four waves longest-first (the schedule
+//     is a few integers computed by every thread from the channel split: no host tables)
+//   * outputs go straight to global memory, 16 bytes per (pixel, chunk); lanes of a task are ordered chunk-fastest
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int MT_TH = 8, MT_TW = 16, MT_WAVES = 4;
+
+__host__ __device__ inline int mt_sp(int K, bool pure_small) { return K >= 7 ? 2 : (K == 5 ? 4 : (pure_small ? 4 : 8)); }
+__host__ __device__ inline int mt_group_of(const MixP& p, int channel) {
+  return channel >= p.split[3] ? 3 : (channel >= p.split[2] ? 2 : (channel >= p.split[1] ? 1 : 0));
+}
+
+template <int K, int SP>
+__device__ __forceinline__ void mt_task(const MixP& p, const uint4* __restrict__ sx, int pitch, int ppx, int pad, const float* __restrict__ swf,
+                                        int first, int units, bf16_t* __restrict__ y, int n, int h0, int w0, int chunk0, int accumulate, int lane) {
+  constexpr int STRIPS = MT_TW / SP;
+  const int items = units * MT_TH * STRIPS;
+  const int off = pad - K / 2;                                  // this kernel size's window inside the slab's halo
+  for (int i = lane; i < items; i += 64) {
+    const int u = i % units, rs = i / units;
+    const int r = rs / STRIPS, sidx = rs - r * STRIPS;
+    const int j = first + u;                                    // chunk inside the slab
+    const float* wj = swf + (size_t)u * K * K * 8;              // this chunk's float32 taps [K][K][8]
+    float acc[SP][8];
+#pragma unroll
+    for (int o = 0; o < SP; ++o)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[o][c] = 0.f;
+#pragma unroll 1
+    for (int dh = 0; dh < K; ++dh) {            // a real loop: unrolled, the compiler hoists all K*K weight rows and spills
+      float wt[K][8];
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const float4 wa = *reinterpret_cast<const float4*>(wj + (dh * K + q) * 8), wb = *reinterpret_cast<const float4*>(wj + (dh * K + q) * 8 + 4);
+        wt[q][0] = wa.x; wt[q][1] = wa.y; wt[q][2] = wa.z; wt[q][3] = wa.w; wt[q][4] = wb.x; wt[q][5] = wb.y; wt[q][6] = wb.z; wt[q][7] = wb.w;
+      }
+      const uint4* xr = sx + (r + dh + off) * pitch + (sidx * SP + off) * ppx + j;
+#pragma unroll
+      for (int ic = 0; ic < SP + K - 1; ++ic) {
+        float xv[8];
+        unpack_bf8(xr[ic * ppx], xv);
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const int o = ic - q;
+          if (o >= 0 && o < SP) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[o][c] += xv[c] * wt[q][c];
+          }
+        }
+      }
+    }
+    const int h = h0 + r;
+    if (h < p.H) {
+      bf16_t* yrow = y + ((size_t)(n * p.H + h) * p.W) * p.C + (size_t)(chunk0 + j) * 8;
+#pragma unroll
+      for (int o = 0; o < SP; ++o) {
+        const int wq = w0 + sidx * SP + o;
+        if (wq < p.W) {
+          bf16_t* yo = yrow + (size_t)wq * p.C;
+          if (accumulate) {
+            float old[8];
+            unpack_bf8(ld16(yo), old);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[o][c] += old[c];
+          }
+          *reinterpret_cast<uint4*>(yo) = pack_bf8(acc[o]);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(MT_WAVES * 64, 2) void dwconv_mix_tiled_kernel(MixP p, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w0,
+                                                                          const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
+                                                                          const bf16_t* __restrict__ w3, bf16_t* __restrict__ y, int flip,
+                                                                          int accumulate, int tiles_w, int tiles_h) {
+  extern __shared__ __attribute__((aligned(16))) uint4 dw_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cvs = p.C >> 3;
+  const int chunk0 = blockIdx.y * 8, nch = min(8, cvs - chunk0);
+  // kernel sizes of the slab's chunks -> halo and the wave-task table, ONCE per workgroup (the kernel-argument lookups behind p.ksize[group]
+  // are dependent scalar loads: recomputed per tile they cost more than the tile's arithmetic)
+  __shared__ int t_K[16], t_first[16], t_units[16], t_woff[16], t_owner[16], t_meta[4];
+  if (tid == 0) {
+    int pad_ = 0, nt_ = 0, woff = 0, total = 0;
+    bool small = true;
+    for (int j = 0; j < nch; ++j) {
+      const int K = p.ksize[mt_group_of(p, (chunk0 + j) * 8)];
+      pad_ = max(pad_, K / 2);
+      small = small && K <= 3;
+      total += K * K;
+    }
+    for (int j = 0; j < nch;) {                                 // runs of equal kernel size cut into <= 64-lane pieces
+      const int K = p.ksize[mt_group_of(p, (chunk0 + j) * 8)];
+      int run = 1;
+      while (j + run < nch && p.ksize[mt_group_of(p, (chunk0 + j + run) * 8)] == K) ++run;
+      const int upw = max(1, 64 / (MT_TH * (MT_TW / mt_sp(K, small))));          // units (chunks) per wave pass
+      for (int f = 0; f < run; f += upw, ++nt_) {
+        t_K[nt_] = K; t_first[nt_] = j + f; t_units[nt_] = min(upw, run - f); t_woff[nt_] = woff + f * K * K * 8;
+      }
+      woff += run * K * K * 8;
+      j += run;
+    }
+    for (int k = 0; k < nt_; ++k) {                             // dealt in snake order from the most expensive end (kernel sizes grow with the
+      const int ph = (nt_ - 1 - k) % (2 * MT_WAVES);            // chunk index): 0 1 2 3 3 2 1 0 ...
+      t_owner[k] = ph < MT_WAVES ? ph : 2 * MT_WAVES - 1 - ph;
+    }
+    t_meta[0] = pad_; t_meta[1] = nt_; t_meta[2] = small ? 1 : 0; t_meta[3] = total;
+  }
+  __syncthreads();
+  const int pad = t_meta[0], nt = t_meta[1];
+  const bool pure_small = t_meta[2] != 0;
+  // ---- stage: float32 weights of the slab (taps flipped for the data gradient), then the halo'd input tile ----
+  const int trows = MT_TH + 2 * pad, tcols = MT_TW + 2 * pad;
+  const int ppx = nch + 1;                                      // chunks per LDS pixel: one pad chunk, so that lanes 2 / 4 / 8 pixels apart
+  const int pitch = tcols * ppx + 1;                            // (and rows) land on different bank quads
+  uint4* sx = dw_smem;
+  float* swf = reinterpret_cast<float*>(dw_smem + trows * pitch);
+  {
+    // one flat pass over all taps of all chunks (a loop per chunk would wait for global memory once per chunk)
+    const int total = t_meta[3];
+    for (int t = tid; t < total; t += MT_WAVES * 64) {
+      int j = 0, base = 0;
+      for (;;) {
+        const int K = p.ksize[mt_group_of(p, (chunk0 + j) * 8)];
+        if (t < base + K * K) break;
+        base += K * K; ++j;
+      }
+      const int g = mt_group_of(p, (chunk0 + j) * 8), K = p.ksize[g], cg = p.split[g + 1] - p.split[g];
+      const bf16_t* w = g == 0 ? w0 : (g == 1 ? w1 : (g == 2 ? w2 : w3));
+      const int cl = (chunk0 + j) * 8 - p.split[g];            // first channel of the chunk inside its group
+      const int tap = t - base, r = tap / K, q = tap - r * K;
+      float f[8];
+      unpack_bf8(ld16(w + (size_t)((flip ? K - 1 - r : r) * K + (flip ? K - 1 - q : q)) * cg + cl), f);
+      float* d = swf + (size_t)t * 8;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d[c] = f[c];
+    }
+  }
+  const int ntiles = p.N * tiles_h * tiles_w;
+  for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {   // persistent over tiles: weights and schedule are per workgroup
+  int tile = tile_id;
+  const int tx = tile % tiles_w; tile /= tiles_w;
+  const int ty = tile % tiles_h;
+  const int n = tile / tiles_h;
+  const int h0 = ty * MT_TH, wc0 = tx * MT_TW;
+  __syncthreads();                                              // the previous tile's readers are done (and the weights are staged)
+  {
+    // thread = (chunk j fixed, pixel q advancing by threads / nch): row / column by carry, no divisions in the loop
+    const int step = (MT_WAVES * 64) / nch;                     // nch divides 256 (1, 2, 4 or 8 chunks)
+    const int j = tid % nch;
+    int q = tid / nch;
+    int row = q / tcols, col = q - row * tcols;
+    const int drow = step / tcols, dcol = step - drow * tcols;
+    for (; row < trows; ) {
+      const int h = h0 - pad + row, wq = wc0 - pad + col;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (h >= 0 && h < p.H && wq >= 0 && wq < p.W) v = ld16(x + ((size_t)(n * p.H + h) * p.W + wq) * p.C + (size_t)(chunk0 + j) * 8);
+      sx[row * pitch + col * ppx + j] = v;
+      row += drow; col += dcol;
+      if (col >= tcols) { col -= tcols; ++row; }
+    }
+  }
+  __syncthreads();
+  // ---- wave-tasks ----
+  for (int k = 0; k < nt; ++k) {
+    if (t_owner[k] != wave) continue;                           // wave-uniform
+    const int K = t_K[k], first = t_first[k], units = t_units[k];
+    const float* wk = swf + t_woff[k];
+#define MT_RUN(K_, SP_) mt_task<K_, SP_>(p, sx, pitch, ppx, pad, wk, first, units, y, n, h0, wc0, chunk0, accumulate, lane)
+    switch (K) {
+      case 1: MT_RUN(1, 8); break;
+      case 3: if (pure_small) MT_RUN(3, 4); else MT_RUN(3, 8); break;
+      case 5: MT_RUN(5, 4); break;
+      case 7: MT_RUN(7, 2); break;
+      default: MT_RUN(9, 2); break;
+    }
+#undef MT_RUN
+  }
+  }   // tiles
+}
+
 // wgrad for one kernel size, ONE pass over the data: thread = (pixel lane, kernel row dh, chunk); per (row, strip) item it reads the dy
 // strip (shared by the K kernel-row threads: LDS broadcast) and the x row segment of its kernel row and accumulates the K taps of that
 // row for 8 channels in registers across all tiles of the workgroup; one LDS reduction over the pixel lanes at the very end, and the
@@ -266,6 +455,9 @@ __global__ __launch_bounds__(256) void dwconv_mix_wgrad_reduce_kernel(SlabSet s,
 constexpr int DW_BLOCKS = 256;   // workgroups per channel group (grid.x); every one loops over its share of the row tiles
 constexpr size_t DW_LDS = 4096 * 16 + 81 * 4 * 16;   // tile budget + the largest weight block (K = 9, cvb = 4)
 
+int g_dw_grid = 512;
+int g_dw_tiled = 1;              // "dw_tiled": 1 (default) tiled forward / data gradient, 0 the row-tile kernel
+
 int check_mix(const yolo_mixconv_problem* p) {
   YOLO_CHECK_ARG(p != nullptr, "null problem");
   YOLO_CHECK_ARG(p->N > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->C % 8 == 0, "bad dims");
@@ -307,6 +499,23 @@ int launch_mix(const yolo_mixconv_problem* p, const void* x, const void* w0, con
   if (rc) return rc;
   YOLO_CHECK_ARG(x && y && w0 && w1 && w2 && w3, "null pointer");
   if ((rc = allow_big_lds())) return rc;
+  if (g_dw_tiled) {
+    const int tiles_h = (p->H + MT_TH - 1) / MT_TH, tiles_w = (p->W + MT_TW - 1) / MT_TW, slabs = (p->C / 8 + 7) / 8;
+    // LDS: halo'd tile of the widest kernel (pad 4) x 8 chunks + float32 taps of 8 chunks of the largest kernel
+    const size_t lds = (size_t)(MT_TH + 8) * ((MT_TW + 8) * 9 + 1) * 16 + (size_t)8 * 81 * 8 * 4;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_mix_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+      attr = true;
+    }
+    const int ntile = p->N * tiles_h * tiles_w, gx = ntile < g_dw_grid ? ntile : g_dw_grid;      // persistent: a few workgroups per CU and slab loop over the tiles
+    hipLaunchKernelGGL(dwconv_mix_tiled_kernel, dim3(gx, slabs), dim3(MT_WAVES * 64), lds, (hipStream_t)stream, to_dev(p),
+                       (const bf16_t*)x, (const bf16_t*)w0, (const bf16_t*)w1, (const bf16_t*)w2, (const bf16_t*)w3, (bf16_t*)y, flip, accumulate,
+                       tiles_w, tiles_h);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+  }
   hipLaunchKernelGGL(dwconv_mix_kernel, dim3(DW_BLOCKS, 4), dim3(DW_THREADS), DW_LDS, (hipStream_t)stream, to_dev(p), (const bf16_t*)x,
                      (const bf16_t*)w0, (const bf16_t*)w1, (const bf16_t*)w2, (const bf16_t*)w3, (bf16_t*)y, flip, accumulate);
   YOLO_LAUNCH_CHECK();
@@ -323,6 +532,8 @@ void wgrad_slabs(const yolo_mixconv_problem* p, int (&count)[4], int (&n)[4]) {
 }
 
 }  // namespace
+
+int yolo_dw_set_tiled(int on) { if (on > 1) { g_dw_grid = on; g_dw_tiled = 1; } else g_dw_tiled = on ? 1 : 0; return YOLO_OK; }   // > 1: persistent grid per slab
 
 extern "C" int yolo_dwconv_mix_fwd(const yolo_mixconv_problem* p, const void* x, const void* w0, const void* w1, const void* w2,
                                    const void* w3, void* y, void* stream) {
