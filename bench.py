@@ -283,6 +283,7 @@ def main():
         model.g.wgrad_stream = torch.cuda.Stream(device=device, priority=args.side_priority)
         model.g.use_side_stream(model.g.wgrad_stream)
     if args.main_priority:
+        torch.cuda.synchronize(device)          # the model was built on the default stream; streams made here do not wait for it implicitly
         torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=args.main_priority))
     if args.wgrad_batch is not None:
         model.g.wgrad_batch = max(1, args.wgrad_batch)
