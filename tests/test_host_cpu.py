@@ -161,3 +161,47 @@ def test_screenshot_is_below_the_xy_loss_floor():
     assert np.sort(floor)[:3].mean() > 4 * xy_shot             # no 3-image batch can show the screenshot's xy terms
     assert floor.mean() > shot['loss']                         # the xy terms alone exceed the screenshot's whole epoch loss
     assert floor.mean() == pytest.approx(24.38, abs=0.05)
+
+
+@pytest.mark.parametrize('name,cls,expect', [('sgdm', 'SGD', dict(lr=0.0002, momentum=0.95, nesterov=True)),
+                                             ('adam', 'Adam', dict(lr=0.0002, amsgrad=True, beta_1=0.9, beta_2=0.999)),
+                                             ('radam', 'RAdam', dict(lr=0.001, amsgrad=False))])
+def test_trainer_selects_the_reference_optimizers(mocked_kernels, tmp_path, monkeypatch, name, cls, expect):
+    """reference trainer.py:69-75: SGD(lr=FLAGS.init_lr, momentum=0.95, nesterov=True) unless FLAGS.optimizer is 'adam'
+    (Adam(lr=FLAGS.init_lr, amsgrad=True)) or 'radam' (RAdam(lr=1e-3), which ignores init_lr); an update launches the schedule of that
+    optimizer's kind once, as one launch or as one per gradient bucket"""
+    from yolov3_tensorflow_amd import configs
+    F = configs.FLAGS
+    saved = dict(F)
+    try:
+        F.update(configs.DEFAULTS)
+        F.optimizer, F.root_path, F.input_image_size, F.batch_size = name, str(tmp_path) + os.sep, np.array([64, 96, 3]), 2
+        configs.refresh_derived()
+        monkeypatch.delenv('WORLD_SIZE', raising=False)
+        from yolov3_tensorflow_amd.yolov3.trainer import YOLOv3Trainer
+        from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
+        build = YOLOv3Detector.build
+        monkeypatch.setattr(YOLOv3Detector, 'build', lambda self, *a, **k: build(self, *a, **dict(k, device='cpu')))     # graph on the CPU, kernels mocked
+        tr = YOLOv3Trainer()
+        opt = tr.optimizer
+        assert type(opt).__name__ == cls and tr.batch_size == 2
+        for k, v in expect.items():
+            assert getattr(opt, k) == pytest.approx(v) if isinstance(v, float) else getattr(opt, k) == v, k
+        assert F.type == 'resnet-18-%s-aug' % name and tr.checkpoint_path.endswith('lp-recognition-resnet-18-%s-aug-{epoch: 3d}-{loss: .5f}.ckpt' % name)
+        tr.model.overlap_wgrad = False            # no HIP streams on the CPU
+        mocked_kernels.clear()
+        tr.model._fwd_bwd()
+        tr.model._update()
+        c = collections.Counter(mocked_kernels)
+        assert c['radam_l2_step'] == 1 and c['sum_partials'] == 2                     # the update + the loss / L2 reduction pair
+        assert (c['radam_schedule'], c['optimizer_schedule']) == ((1, 0) if name == 'radam' else (0, 1))
+        mocked_kernels.clear()
+        for i, (lo, hi) in enumerate(tr.model.g.bucket_ranges):                       # the per-bucket form the training step uses
+            opt.launch_range(tr.model, lo, hi, i == 0)
+        opt.finish(tr.model)
+        c = collections.Counter(mocked_kernels)
+        assert c['radam_l2_step'] == 3 and c['radam_schedule'] + c['optimizer_schedule'] == 1 and c['sum_partials'] == 2
+        assert sum(hi - lo for lo, hi in tr.model.g.bucket_ranges) == tr.model.g.ps.n
+    finally:
+        F.clear()
+        F.update(saved)
