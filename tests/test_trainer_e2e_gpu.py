@@ -52,7 +52,8 @@ def test_train_checkpoint_tensorboard_and_test_mode(tmp_path, caplog):
         # checkpoints: '<name>-{epoch: 3d}-{loss: .5f}.ckpt' + 'checkpoint' pointer file (reference configs.py:94, trainer.py:57-64)
         ckdir = os.path.dirname(FLAGS.checkpoint_path)
         files = sorted(os.listdir(ckdir))
-        assert 'checkpoint' in files and sum('.ckpt' in f for f in files) == 2, files
+        # TensorFlow's checkpoint files: <stem>.index + <stem>.data-00000-of-00001 per checkpoint (utils/tf_checkpoint.py)
+        assert 'checkpoint' in files and sum(f.endswith('.ckpt.index') for f in files) == 2 and sum(f.endswith('.ckpt.data-00000-of-00001') for f in files) == 2, files
         assert any('-  1- ' in f or '-  1-' in f for f in files) and any('-  2-' in f for f in files), files
         # TensorBoard layout: main + 18 sub-loss dirs + bn_gamma, every record CRC-valid, 2 epochs each
         tb = FLAGS.tensorboard_dir
