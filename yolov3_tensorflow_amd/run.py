@@ -23,7 +23,9 @@ def train(yolov3_trainer):
     # FLAGS.batch_size is the global batch; under torchrun every rank reads its slice of it (FileUtil.host_batches)
     train_dataset = FileUtil.get_dataset(FLAGS.train_label_path, FLAGS.train_set_dir, image_size=FLAGS.input_image_size[0:2],
                                          batch_size=yolov3_trainer.batch_size, is_augment=FLAGS.is_augment, is_test=False)
-    yolov3_trainer.train(train_dataset, None)
+    # (the trainer's defaults for these two are bound when its module is imported, as in the reference, trainer.py:99; FLAGS edited after that
+    #  import are honoured by passing the current values)
+    yolov3_trainer.train(train_dataset, None, train_steps=FLAGS.steps_per_epoch, val_steps=FLAGS.validation_steps)
     logging.info('training finished')
 
 
