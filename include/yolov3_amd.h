@@ -95,6 +95,17 @@ int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* sr
 /* dx[N,H,W,Cin] (=|+=) conv_transpose(dy[N,Ho,Wo,Cout], w).  Cin must be a multiple of 64.  accumulate != 0 adds into dx. */
 int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
                       void* stream);
+/* The same with the BatchNorm-backward REDUCE of the unit whose output gradient dx is, in the epilogue (the reference differentiates
+ * Conv2D -> BatchNormalization -> ReLU chains by autodiff, basic_backbone.py:68-90; this is that chain's backward pass without the
+ * separate statistics pass): dx receives the MASKED gradient g = (accumulated) dx where the unit's ReLU was positive (relu_mask: the sign
+ * bytes of yolo_bn_act_fwd_mask, null for a linear unit), and partial[rows][3][Cin] (rows = yolo_conv2d_dgrad_bn_rows(p), allocated
+ * ZEROED by the caller) the per-tile sums of g, g*xhat(y, mean, rstd) and, with y2, g*xhat(y2, mean2, rstd2).  yolo_bn_bwd_finalize over
+ * `partial` and yolo_bn_act_bwd_apply(relu = 0) on dx finish the unit.  No grid barrier: safe next to collective kernels.
+ * yolo_conv2d_dgrad_bn_rows < 0: this problem cannot take the fused form (N*H*W*Cin >= 2^31). */
+int yolo_conv2d_dgrad_bn_rows(const yolo_conv_problem* p);
+int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                         const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2,
+                         const float* mean2, const float* rstd2, float* partial, void* stream);
 /* dw[Cout][R][S][Cin] += x^T * dy (float32 atomics; the caller zeroes dw once per step).  split_k <= 0 = auto. */
 int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
                       int split_k, void* stream);
@@ -148,6 +159,11 @@ int yolo_bn_bwd_finalize_grouped(const float* partial, int P, int64_t row_stride
 /* out = act(y*scale + shift + T); T = 0 (res NULL), res (res_scale NULL) or res*res_scale + res_shift; scale NULL = identity */
 int yolo_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
                     const float* res_shift, void* out, int64_t M, int C, int relu, void* stream);
+/* The ReLU form that also leaves the activation's sign as a BYTE MASK, relu_mask[M][C/8] (bit j of byte (m, c/8) = channel 8*(c/8)+j of pixel m
+ * is positive).  The backward entry points below accept it in place of `out` with relu = 2: they then read 1 byte instead of 16 per chunk
+ * (BatchNorm backward is pure HBM traffic: dout + out + y in, dy out; the mask removes a quarter of it). */
+int yolo_bn_act_fwd_mask(const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+                         const float* res_shift, void* out, uint8_t* relu_mask, int64_t M, int C, void* stream);
 /* out[N,Ho,Wo,C] = act(maxpool3x3s2(y*scale + shift)); argmax[N,Ho,Wo,C] = window position 0..8 of the first maximum */
 int yolo_bn_pool_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax, int N, int H, int W, int C,
                      int Ho, int Wo, int pad_t, int pad_l, int relu, void* stream);

@@ -72,7 +72,7 @@ def mocked_kernels(monkeypatch):
         fn = getattr(ops, name)
         if callable(fn) and getattr(fn, '__module__', None) == ops.__name__ and name not in (
                 'same_pad', 'conv_problem', 'mix_problem', 'pad_channels', 'make_loss_config', 'conv2d_stat_rows', 'reduce_rows', 'radam_l2_blocks',
-                'loss_workspace_bytes', 'check', '_p', '_stream', 'conv2d_wgrad_workspace_bytes', 'conv2d_wgrad_splits', 'bn_bwd_fused_workspace_floats', 'bn_bwd_fused_sync_words', 'dwconv_mix_wgrad_workspace_bytes'):
+                'loss_workspace_bytes', 'check', '_p', '_stream', 'conv2d_wgrad_workspace_bytes', 'conv2d_wgrad_splits', 'conv2d_dgrad_bn_rows', 'bn_bwd_fused_workspace_floats', 'bn_bwd_fused_sync_words', 'dwconv_mix_wgrad_workspace_bytes'):
             monkeypatch.setattr(ops, name, (lambda n: (lambda *a, **k: calls.append(n)))(name))
     monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
     monkeypatch.setattr(torch.cuda, 'current_device', lambda: 0)

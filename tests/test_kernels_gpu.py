@@ -147,6 +147,117 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
         torch.testing.assert_close(dx.float().cpu(), 2 * xr.grad, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize('C,M,res', [(64, 5000, False), (128, 2704 * 4, True), (512, 700, True)])
+def test_relu_byte_mask_equals_reading_the_activation(dev, C, M, res):
+    """bn_act_fwd(mask=...) leaves the activation's sign bits, one byte per 8-channel chunk; every BatchNorm-backward entry point given that mask
+    (relu = 2) produces bit-identical results to the same call reading the 16-bit activation itself (relu = 1)"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(C + M)
+    y = bf(torch.randn(M, C, generator=g)).to(dev)
+    r = bf(torch.randn(M, C, generator=g)).to(dev) if res else None
+    scale, shift = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    out = torch.empty(M, C, dtype=ACT(), device=dev)
+    out2 = torch.empty_like(out)
+    mask = torch.zeros(M * C // 8, dtype=torch.uint8, device=dev)
+    ops.bn_act_fwd(y, scale, shift, out, M, C, True, res=r, mask=mask)
+    ops.bn_act_fwd(y, scale, shift, out2, M, C, True, res=r)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    bits = (out.float() > 0).reshape(M, C // 8, 8).to(torch.int32)
+    want = (bits * (2 ** torch.arange(8, device=dev, dtype=torch.int32))).sum(-1).to(torch.uint8).reshape(-1)
+    assert torch.equal(mask, want)
+    dout = bf(torch.randn(M, C, generator=g)).to(dev)
+    mean, rstd = (torch.randn(C, generator=g) * 0.1).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+    P = ops.reduce_rows(M, C)
+    res_ = []
+    for sign, code in ((out, 1), (mask, 2)):
+        part = torch.zeros(P, 3, C, device=dev)
+        ops.bn_act_bwd_reduce(dout, sign, code, y, mean, rstd, M, C, part)
+        k1, k2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        ops.bn_bwd_finalize(part.view(-1), P, C, 1, M, dg, db, k1, k2, row_stride=3 * C, q_stride=C)
+        dy = torch.empty(M, C, dtype=ACT(), device=dev)
+        dres = torch.empty(M, C, dtype=ACT(), device=dev) if res else None
+        ops.bn_act_bwd_apply(dout, sign, code, M, C, y=y, a1=scale, mean=mean, rstd=rstd, k1=k1, k2=k2, dy=dy, dres=dres)
+        ws = torch.zeros(ops.bn_bwd_fused_workspace_floats(C), device=dev)
+        sync = torch.zeros(ops.bn_bwd_fused_sync_words(), dtype=torch.int32, device=dev)
+        dg2, db2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dy2 = torch.empty(M, C, dtype=ACT(), device=dev)
+        dres2 = torch.empty(M, C, dtype=ACT(), device=dev) if res else None
+        ops.set_tuning('bn_fused_min_chunks', 1)
+        try:
+            fused = ops.bn_act_bwd_fused(dout, sign, code, M, C, y, scale, mean, rstd, dg2, db2, dy2, ws, sync, dres=dres2)
+        finally:
+            ops.set_tuning('bn_fused_min_chunks', 3)
+        torch.cuda.synchronize()
+        assert fused
+        res_.append([t.clone() for t in (part, dg, db, dy, dy2, dg2, db2) + ((dres, dres2) if res else ())])
+    for a_, b_ in zip(*res_):
+        assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize('case', [
+    # N, H, W, Cin, Cout, k, stride, accumulate, relu, shortcut BN      (tile the data-gradient kernel picks)
+    (2, 104, 104, 64, 64, 3, 1, True, True, False),      # strip 256 x 64
+    (4, 52, 52, 128, 128, 3, 1, False, True, False),     # strip 128-pixel tiles
+    (4, 26, 26, 256, 256, 3, 1, True, True, True),       # strip, shortcut-BN quantity
+    (3, 13, 13, 512, 256, 3, 1, True, True, False),      # strip 64-pixel tiles, ragged last tile
+    (3, 13, 13, 512, 1024, 1, 1, False, False, False),   # 1x1 (implicit GEMM), linear unit (no mask)
+    (2, 52, 52, 64, 128, 3, 2, True, True, False),       # stride 2: four parity classes
+    (2, 26, 30, 128, 256, 1, 2, False, True, True),      # 1x1 stride 2 (strided gather)
+    (1, 27, 27, 64, 64, 3, 2, True, True, False),        # stride 2 on an odd map: classes of different sizes
+])
+def test_dgrad_with_bn_reduce_epilogue(dev, case):
+    """conv2d_dgrad(bn=...) = the plain data gradient followed by the unit's masked reduce: dx holds the masked gradient bit for bit and
+    the tile sums add up to what bn_act_bwd_reduce computes from the plain result (float32 sums in a different order)"""
+    from yolov3_tensorflow_amd import ops
+    N, H, W, Cin, Cout, k, s, acc, relu, has2 = case
+    g = torch.Generator().manual_seed(sum(case[:7]))
+    p = ops.conv_problem(N, H, W, Cin, Cout, k, s, 'same')
+    w = bf(torch.randn(Cout, k, k, Cin, generator=g) * 0.05).to(dev)
+    w_dg = torch.empty(Cin, k, k, Cout, dtype=ACT(), device=dev)
+    ops.repack_dgrad_weights(w, w_dg, Cout, k, k, Cin)
+    dy = bf(torch.randn(N, p.Ho, p.Wo, Cout, generator=g)).to(dev)
+    base = bf(torch.randn(N, H, W, Cin, generator=g)).to(dev)
+    M = N * H * W
+    y = bf(torch.randn(M, Cin, generator=g) * 1.3 + 0.2).to(dev)
+    y2 = bf(torch.randn(M, Cin, generator=g)).to(dev) if has2 else None
+    mean, rstd = (torch.randn(Cin, generator=g) * 0.2).to(dev), (torch.rand(Cin, generator=g) + 0.5).to(dev)
+    mean2, rstd2 = ((torch.randn(Cin, generator=g) * 0.2).to(dev), (torch.rand(Cin, generator=g) + 0.5).to(dev)) if has2 else (None, None)
+    mask = torch.randint(0, 256, (M * Cin // 8,), generator=g, dtype=torch.uint8).to(dev) if relu else None
+
+    plain = base.clone()
+    ops.conv2d_dgrad(p, dy, w_dg, plain, accumulate=acc)
+    rows = ops.conv2d_dgrad_bn_rows(p)
+    assert rows > 0
+    partial = torch.zeros(rows, 3, Cin, device=dev)
+    fused = base.clone()
+    bn = dict(mask=mask, y=y, mean=mean, rstd=rstd, partial=partial)
+    if has2:
+        bn.update(y2=y2, mean2=mean2, rstd2=rstd2)
+    ops.conv2d_dgrad(p, dy, w_dg, fused, accumulate=acc, bn=bn)
+    torch.cuda.synchronize()
+    want = plain.reshape(M, Cin // 8, 8).float()
+    if relu:
+        bits = ((mask.to(torch.int32).reshape(M, Cin // 8, 1) >> torch.arange(8, device=dev, dtype=torch.int32)) & 1).float()
+        want = want * bits
+    want = want.reshape(M, Cin)
+    assert torch.equal(fused.reshape(M, Cin).float(), want)
+    # reference sums from the existing reduce kernel on the plain result
+    P = ops.reduce_rows(M, Cin)
+    ref = torch.zeros(P, 3, Cin, device=dev)
+    ops.bn_act_bwd_reduce(plain, mask, 2 if relu else 0, y, mean, rstd, M, Cin, ref, y2=y2, mean2=mean2, rstd2=rstd2)
+    torch.cuda.synchronize()
+    nq = 3 if has2 else 2
+    got, exp = partial.double().sum(0)[:nq], ref.double().sum(0)[:nq]
+    scale = float(exp.abs().max())
+    torch.testing.assert_close(got, exp, rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+    # and in double from the masked gradient itself
+    gd, yd = want.double(), y.double()
+    torch.testing.assert_close(got[0], gd.sum(0), rtol=1e-5, atol=1e-5 * max(scale, 1.0))
+    torch.testing.assert_close(got[1], (gd * ((yd - mean.double()) * rstd.double())).sum(0), rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+
+
 def test_stem_kernel_matches_implicit_gemm(dev):
     """the row-walking stem kernel against the implicit-GEMM kernel on the same input (yolo_set_tuning 'stem_direct'): same values up to the
     float32 accumulation order (K is laid out tap-major with 4-channel taps there, 8-channel taps here), statistics rows sum to the same totals"""

@@ -60,6 +60,8 @@ SIGNATURES = {
     'yolo_set_tuning': (I, [C.c_char_p, I]),
     'yolo_conv2d_fwd': (I, [CP, P, P, P, P, P, I, P, P, P]),
     'yolo_conv2d_dgrad': (I, [CP, P, P, P, I, P]),
+    'yolo_conv2d_dgrad_bn_rows': (I, [CP]),
+    'yolo_conv2d_dgrad_bn': (I, [CP, P, P, P, I, P, P, P, P, P, P, P, P, P]),
     'yolo_conv2d_wgrad': (I, [CP, P, P, P, P, I, P]),
     'yolo_conv2d_wgrad_workspace_bytes': (C.c_size_t, [CP]),
     'yolo_conv2d_wgrad_reduce': (I, [CP, P, P, P, P, P, C.c_size_t, I, P]),
@@ -74,6 +76,7 @@ SIGNATURES = {
     'yolo_bn_finalize_grouped': (I, [P, P, I, C.c_int64, I, C.c_float, I, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P]),
     'yolo_bn_bwd_finalize_grouped': (I, [P, I, C.c_int64, C.c_int64, I, I, C.c_float, I, P, P, P, P, P, P]),
     'yolo_bn_act_fwd': (I, [P, P, P, P, P, P, P, I64, I, I, P]),
+    'yolo_bn_act_fwd_mask': (I, [P, P, P, P, P, P, P, P, I64, I, P]),
     'yolo_bn_pool_fwd': (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     'yolo_bn_act_bwd_reduce': (I, [P, P, I, P, P, P, P, P, P, I, I, P, P]),
     'yolo_bn_bwd_finalize': (I, [P, I, I64, I64, I, I, F, P, P, P, P, P]),

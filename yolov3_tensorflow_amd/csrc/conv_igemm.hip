@@ -46,6 +46,18 @@ struct Gather {
 // per-launch view of the class a workgroup works on
 struct ClassView { int on, wbase, wdr, wds, two, Hc, Wc, OH, OW, ph, pw; float rhw, rw; };
 
+// BatchNorm-backward reduce fused into the data-gradient epilogue: the tile being written IS dL/d(out) of a BN(+ReLU)(+residual) unit, so
+// the epilogue masks it with the unit's ReLU sign bits (mask: one byte per 8-channel chunk, or null), stores the masked gradient g and
+// leaves the per-channel partial sums  sum g,  sum g xhat  (and  sum g xhat2  of a shortcut BN) of its tile in partial[row][3][ld] --
+// the separate reduce pass over dout / out / y (and the grid barrier of the single-launch form) disappears.  partial == null: off.
+struct BnEpi {
+  const uint8_t* mask;
+  const bf16_t* y;  const float* mean;  const float* rstd;
+  const bf16_t* y2; const float* mean2; const float* rstd2;
+  float* partial;
+};
+struct Epi { float* ssum; float* ssq; BnEpi bn; };
+
 struct RowInfo { int n, hb, wb; };
 
 // full-rate 24-bit multiply-add (operands < 2^24; the 32-bit v_mul_lo_u32 is quarter rate)
@@ -125,10 +137,11 @@ constexpr int BK = 64;  // K elements per stage
 // Tile epilogue shared by the conv kernels: lane holds channels co..co+3 (rows of D) of pixel (column of D); acc[a][b] = channel tile a x
 // pixel tile b of this wave (wave grid WM pixels x WN channels).  bf16 outputs are staged through LDS (the operand buffers are free by
 // then), optional BatchNorm partial statistics go to one row per pixel tile.
-template <int BM, int BN, int NW, int WM, int WN, int PT, int CT, bool OUT_F32>
+template <int BM, int BN, int NW, int WM, int WN, int PT, int CT, bool OUT_F32, bool BNEPI = false>
 __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem, int M, int m0, int n0, int tile_m, const float* __restrict__ bias,
                                               void* __restrict__ Yv, int ldy, int accumulate, float* __restrict__ stat_sum,
-                                              float* __restrict__ stat_sq, int Kout, int tid, int lane, int wm, int wn, const ClassView& cv) {
+                                              float* __restrict__ stat_sq, int Kout, int tid, int lane, int wm, int wn, const ClassView& cv,
+                                              const BnEpi& bn, int prow) {
   const int cq = (lane >> 4) * 4;
   float ssum[CT][4], ssq[CT][4];
 #pragma unroll
@@ -182,6 +195,83 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
     __syncthreads();
     constexpr int CPR = BN / 8;                       // 16-byte chunks per row
     bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
+    if constexpr (BNEPI) {   // data gradient of a BatchNorm unit's output: mask, store g, partial sums of g and g xhat
+      constexpr int RG = NW * 64 / CPR;               // a thread keeps its channel chunk (NW * 64 is a multiple of CPR) and walks rows
+      constexpr int ITER = BM / RG, NB = ITER < 4 ? ITER : 4;
+      static_assert(BM % RG == 0 && ITER % NB == 0 && RG * BN * 4 <= BM * (BN * 2 + 16), "epilogue geometry");
+      const int ch = tid % CPR, rg = tid / CPR, c = n0 + ch * 8;
+      float mu[8], rs[8], s0[8], s1[8], s2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { mu[j] = bn.mean[c + j]; rs[j] = bn.rstd[c + j]; s0[j] = s1[j] = s2[j] = 0.f; }
+#pragma unroll
+      for (int it0 = 0; it0 < ITER; it0 += NB) {
+        uint4 yv[NB], ev[NB];
+        unsigned mk[NB], off[NB];                     // element offsets (the host refuses tensors of 2^31 elements or more)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {                // the batch's global reads in flight together
+          const int row = rg + (it0 + k) * RG, m = m0 + row;
+          off[k] = 0xffffffffu;
+          if (m < M) {
+            int mo = m;
+            if (cv.on) {
+              int n_, rem, hh, ww;
+              fast_divmod(m, cv.Hc * cv.Wc, cv.rhw, n_, rem);
+              fast_divmod(rem, cv.Wc, cv.rw, hh, ww);
+              mo = (n_ * cv.OH + 2 * hh + cv.ph) * cv.OW + 2 * ww + cv.pw;
+            }
+            off[k] = (unsigned)mo * (unsigned)ldy + (unsigned)c;
+            yv[k] = *reinterpret_cast<const uint4*>(bn.y + off[k]);
+            if (accumulate) ev[k] = *reinterpret_cast<const uint4*>(Y + off[k]);
+            mk[k] = bn.mask ? (unsigned)bn.mask[off[k] >> 3] : 0xffu;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          if (off[k] != 0xffffffffu) {
+            const int row = rg + (it0 + k) * RG;
+            uint4 v = *reinterpret_cast<const uint4*>(smem + row * OLD + ch * 16);
+            float g8[8], y8[8];
+            if (accumulate) {                         // gradient fan-in: float32 add, one rounding (as the plain path below)
+              unpack_bf8(v, g8);
+              unpack_bf8(ev[k], y8);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) g8[j] += y8[j];
+              v = pack_bf8(g8);
+            }
+            unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              w4[q] = (((mk[k] >> (2 * q)) & 1u) ? (w4[q] & 0xffffu) : 0u) | (((mk[k] >> (2 * q + 1)) & 1u) ? (w4[q] & 0xffff0000u) : 0u);
+            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            *reinterpret_cast<uint4*>(Y + off[k]) = v;
+            unpack_bf8(v, g8);
+            unpack_bf8(yv[k], y8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0[j] += g8[j]; s1[j] += g8[j] * ((y8[j] - mu[j]) * rs[j]); }
+            if (bn.y2) {                              // shortcut BatchNorm of a down-sampling block (3 units per step): loaded in place
+              unpack_bf8(*reinterpret_cast<const uint4*>(bn.y2 + off[k]), y8);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s2[j] += g8[j] * ((y8[j] - bn.mean2[c + j]) * bn.rstd2[c + j]);
+            }
+          }
+        }
+      }
+      float* red = reinterpret_cast<float*>(smem);    // [RG][BN], one quantity at a time
+      const int nq = bn.y2 ? 3 : 2;
+      for (int q = 0; q < nq; ++q) {
+        __syncthreads();                              // the staged tile (q = 0) / the previous quantity has been read
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[rg * BN + ch * 8 + j] = q == 0 ? s0[j] : (q == 1 ? s1[j] : s2[j]);
+        __syncthreads();
+        for (int cl = tid; cl < BN; cl += NW * 64) {
+          float t = 0.f;
+#pragma unroll 8
+          for (int r = 0; r < RG; ++r) t += red[r * BN + cl];
+          bn.partial[((size_t)prow * 3 + q) * ldy + n0 + cl] = t;
+        }
+      }
+      return;
+    }
     for (int i = tid; i < BM * CPR; i += NW * 64) {
       const int row = i / CPR, ch = i - row * CPR;
       const int m = m0 + row;
@@ -241,11 +331,11 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
 // s_barrier of each K-step; the XOR swizzle of the LDS image is applied on the SOURCE address (LDS-DMA writes lane-linear).
 // FAST gather (den == 1, single source, <= 32 taps): address = row base + tap offset, validity = one bit of a per-row tap mask, both
 // computed once per tile; the generic path (stride-2 data gradient, fused upsample+concat) recomputes coordinates per K-step.
-template <int BM, int BN, int NSTAGE, bool OUT_F32, bool FAST, int NW>
+template <int BM, int BN, int NSTAGE, bool OUT_F32, bool FAST, int NW, bool BNEPI>
 __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16_t* __restrict__ Wt, const float* __restrict__ bias,
                                                         void* __restrict__ Yv, int ldy, int accumulate,
                                                         float* __restrict__ stat_sum, float* __restrict__ stat_sq,
-                                                        int Kout, int tiles_n) {
+                                                        int Kout, int tiles_n, BnEpi bnepi) {
   constexpr int WN = (BN == 128) ? 2 : 1;  // waves along channels
   constexpr int WM = NW / WN;              // waves along pixels
   constexpr int PT = BM / WM / 16;         // 16-pixel MFMA tiles per wave
@@ -395,8 +485,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16
     compute_stage(kt % NSTAGE);
   }
 
-  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, OUT_F32>(acc, smem, g.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane, wm, wn,
-                                                     cv);
+  // (partial row of a fused BatchNorm reduce: one per pixel tile and parity class; classes smaller than the grid leave theirs untouched = 0)
+  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, OUT_F32, BNEPI>(acc, smem, g.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane, wm, wn,
+                                                     cv, bnepi, (int)(blockIdx.y * (gridDim.x / tiles_n)) + tile_m);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -417,10 +508,10 @@ struct StripArgs {
   float rhw, rw;
 };
 
-template <int BM, int BN, int NW, int WS>
+template <int BM, int BN, int NW, int WS, bool BNEPI>
 __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, const float* __restrict__ bias, void* __restrict__ Yv, int ldy,
                                                             int accumulate, float* __restrict__ stat_sum, float* __restrict__ stat_sq,
-                                                            int Kout, int tiles_n) {
+                                                            int Kout, int tiles_n, BnEpi bnepi) {
   constexpr int WN = (BN == 128) ? 2 : 1;
   constexpr int WM = NW / WN;
   constexpr int PT = BM / WM / 16;
@@ -553,8 +644,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, con
   }
   __syncthreads();   // all waves are done with strip / ring before the epilogue reuses the LDS (tile_epilogue syncs only for bf16 outputs)
   const ClassView cv = {};
-  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, false>(acc, smem, a.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane,
-                                                   wm, wn, cv);
+  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, false, BNEPI>(acc, smem, a.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane,
+                                                   wm, wn, cv, bnepi, tile_m);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1244,8 +1335,8 @@ int stat_rows_for(const Gather& g, int Kout) {
   return (g.M + t.bm - 1) / t.bm;      // one partial row per pixel tile
 }
 
-template <int BM, int BN, int NW, int WS>
-int launch_strip_ws(const Gather& g, const void* w, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout, hipStream_t st) {
+template <int BM, int BN, int NW, int WS, bool BNEPI>
+int launch_strip_ws_e(const Gather& g, const void* w, void* y, int ldy, int accumulate, const Epi& e, int Kout, hipStream_t st) {
   StripArgs a;
   a.src = g.src1;
   a.src_bytes = (unsigned)((size_t)g.M / ((size_t)g.Ho * g.Wo) * g.Hs * g.Ws * g.C1 * 2);
@@ -1258,47 +1349,62 @@ int launch_strip_ws(const Gather& g, const void* w, void* y, int ldy, int accumu
   const size_t lds = lds_main > lds_out ? lds_main : lds_out;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<BM, BN, NW, WS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_strip_kernel<BM, BN, NW, WS, BNEPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
-  hipLaunchKernelGGL((conv3x3_strip_kernel<BM, BN, NW, WS>), dim3(tiles_m * tn), dim3(NW * 64), lds, st, a, nullptr, y, ldy, accumulate, ssum, ssq,
-                     Kout, tn);
+  hipLaunchKernelGGL((conv3x3_strip_kernel<BM, BN, NW, WS, BNEPI>), dim3(tiles_m * tn), dim3(NW * 64), lds, st, a, nullptr, y, ldy, accumulate, e.ssum, e.ssq,
+                     Kout, tn, e.bn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
+}
+
+template <int BM, int BN, int NW, int WS>
+int launch_strip_ws(const Gather& g, const void* w, void* y, int ldy, int accumulate, const Epi& e, int Kout, hipStream_t st) {
+  if (e.bn.partial) return launch_strip_ws_e<BM, BN, NW, WS, true>(g, w, y, ldy, accumulate, e, Kout, st);
+  return launch_strip_ws_e<BM, BN, NW, WS, false>(g, w, y, ldy, accumulate, e, Kout, st);
 }
 
 // third weight stage where three workgroups per CU still fit in the 160 KiB of LDS (measured: +7..14 % on the 26 x 26 / 13 x 13 maps,
 // -25 % where it drops the 104 x 104 maps to one workgroup per CU)
 template <int BM, int BN, int NW>
-int launch_strip(const Gather& g, const void* w, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout, hipStream_t st) {
+int launch_strip(const Gather& g, const void* w, void* y, int ldy, int accumulate, const Epi& e, int Kout, hipStream_t st) {
   const size_t strip = (size_t)((BM + 2 * g.Wo + 2 + 7) / 8 * 8) * 128 + 128, out = (size_t)BM * (BN * 2 + 16);
   auto lds = [&](int ws) { const size_t m = strip + (size_t)ws * BN * 128; return m > out ? m : out; };
   const size_t cap = 160 * 1024;
   if (g_strip_ws != 2 && (g_strip_ws == 3 || cap / lds(3) >= 3) && lds(3) <= cap)
-    return launch_strip_ws<BM, BN, NW, 3>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
-  return launch_strip_ws<BM, BN, NW, 2>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
+    return launch_strip_ws<BM, BN, NW, 3>(g, w, y, ldy, accumulate, e, Kout, st);
+  return launch_strip_ws<BM, BN, NW, 2>(g, w, y, ldy, accumulate, e, Kout, st);
 }
 
-template <int BM, int BN, int NS, bool F32, bool FAST, int NW>
-int launch_tile3(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
+template <int BM, int BN, int NS, bool F32, bool FAST, int NW, bool BNEPI>
+int launch_tile3_e(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, const Epi& e, int Kout,
                 hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
   constexpr size_t lds_ring = NS * (BM * BK * 2 + BN * BK * 2), lds_out = (size_t)BM * (BN * 2 + 16);
   constexpr size_t lds = lds_ring > lds_out ? lds_ring : lds_out;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW, BNEPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW>), dim3(tiles_m * tn, g.s2 ? 4 : 1), dim3(NW * 64), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
-                     ssum, ssq, Kout, tn);
+  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW, BNEPI>), dim3(tiles_m * tn, g.s2 ? 4 : 1), dim3(NW * 64), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
+                     e.ssum, e.ssq, Kout, tn, e.bn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
+}
+
+template <int BM, int BN, int NS, bool F32, bool FAST, int NW>
+int launch_tile3(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, const Epi& e, int Kout,
+                 hipStream_t st) {
+  if constexpr (!F32) {
+    if (e.bn.partial) return launch_tile3_e<BM, BN, NS, F32, FAST, NW, true>(g, w, bias, y, ldy, accumulate, e, Kout, st);
+  }
+  return launch_tile3_e<BM, BN, NS, F32, FAST, NW, false>(g, w, bias, y, ldy, accumulate, e, Kout, st);
 }
 
 // Ring depth: 2 stages (64 KB for 128 x 128: two workgroups per CU; 48 KB for 128 x 64 / 64 x 128: three).  Measured on MI355X
@@ -1306,41 +1412,41 @@ int launch_tile3(const Gather& g, const void* w, const float* bias, void* y, int
 // on these short K loops -- and a ring of finer 32-wide units (64-byte rows) is 30-80 % slower: half-line LDS-DMA pieces double the L2
 // requests, rows must stay whole 128-byte lines.
 template <int BM, int BN, bool F32, bool FAST>
-int launch_tile2(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
+int launch_tile2(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, const Epi& e, int Kout,
                  hipStream_t st) {
   // 128 x 128 tiles run with 8 waves (each 32 pixels x 64 channels): same LDS, twice the waves per SIMD; measured 128-channel layer
   // fwd 56 -> 49 us, dgrad 48 -> 38 us; on 128 x 64 tiles it is mixed (fwd slower), so those keep 4 waves
-  if constexpr (BM == 128 && BN == 128) return launch_tile3<BM, BN, 2, F32, FAST, 8>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
-  else return launch_tile3<BM, BN, 2, F32, FAST, 4>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+  if constexpr (BM == 128 && BN == 128) return launch_tile3<BM, BN, 2, F32, FAST, 8>(g, w, bias, y, ldy, accumulate, e, Kout, st);
+  else return launch_tile3<BM, BN, 2, F32, FAST, 4>(g, w, bias, y, ldy, accumulate, e, Kout, st);
 }
 
 template <int BM, int BN, bool F32>
-int launch_tile(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq, int Kout,
+int launch_tile(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, const Epi& e, int Kout,
                 hipStream_t st) {
   const bool fast = g.den == 1 && g.C0 == 0 && g.S <= 9 && g.RS <= 81 &&
                     (size_t)g.Hs * g.Ws * g.C1 * (size_t)(g.M / (g.Ho * g.Wo) + 1) < (1ull << 31);
-  if (fast) return launch_tile2<BM, BN, F32, true>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
-  return launch_tile2<BM, BN, F32, false>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+  if (fast) return launch_tile2<BM, BN, F32, true>(g, w, bias, y, ldy, accumulate, e, Kout, st);
+  return launch_tile2<BM, BN, F32, false>(g, w, bias, y, ldy, accumulate, e, Kout, st);
 }
 
 template <bool F32>
-int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, float* ssum, float* ssq,
+int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, const Epi& e,
                int Kout, hipStream_t st) {
   int sbn = 0;
   if (const int sb = pick_strip(g, Kout, F32, &sbn)) {
     const bool wide = sbn == 128;
-    if (sb == 64) return wide ? launch_strip<64, 128, 4>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st)
-                              : launch_strip<64, 64, 4>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
-    if (sb == 256) return wide ? launch_strip<256, 128, 8>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st)
-                               : launch_strip<256, 64, 8>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
-    return wide ? launch_strip<128, 128, 8>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st)
-                : launch_strip<128, 64, 4>(g, w, y, ldy, accumulate, ssum, ssq, Kout, st);
+    if (sb == 64) return wide ? launch_strip<64, 128, 4>(g, w, y, ldy, accumulate, e, Kout, st)
+                              : launch_strip<64, 64, 4>(g, w, y, ldy, accumulate, e, Kout, st);
+    if (sb == 256) return wide ? launch_strip<256, 128, 8>(g, w, y, ldy, accumulate, e, Kout, st)
+                               : launch_strip<256, 64, 8>(g, w, y, ldy, accumulate, e, Kout, st);
+    return wide ? launch_strip<128, 128, 8>(g, w, y, ldy, accumulate, e, Kout, st)
+                : launch_strip<128, 64, 4>(g, w, y, ldy, accumulate, e, Kout, st);
   }
   const TileCfg t = pick_tile(g.M, Kout);
-  if (t.bm == 128 && t.bn == 128) return launch_tile<128, 128, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
-  if (t.bm == 128 && t.bn == 64) return launch_tile<128, 64, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
-  if (t.bm == 64 && t.bn == 128) return launch_tile<64, 128, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
-  return launch_tile<64, 64, F32>(g, w, bias, y, ldy, accumulate, ssum, ssq, Kout, st);
+  if (t.bm == 128 && t.bn == 128) return launch_tile<128, 128, F32>(g, w, bias, y, ldy, accumulate, e, Kout, st);
+  if (t.bm == 128 && t.bn == 64) return launch_tile<128, 64, F32>(g, w, bias, y, ldy, accumulate, e, Kout, st);
+  if (t.bm == 64 && t.bn == 128) return launch_tile<64, 128, F32>(g, w, bias, y, ldy, accumulate, e, Kout, st);
+  return launch_tile<64, 64, F32>(g, w, bias, y, ldy, accumulate, e, Kout, st);
 }
 
 }  // namespace
@@ -1387,19 +1493,18 @@ extern "C" int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, con
   YOLO_CHECK_ARG(!(y_is_f32 && stat_sum), "statistics are defined on bf16 outputs only");
   if (!y_is_f32 && !bias && yolo_stem_applies(p)) return yolo_stem_fwd(p, src1, w_fwd, y, stat_sum, stat_sq, stream);   // RGB stem: row-walking kernel
   Gather g = fwd_gather(p, src0, src1);
-  if (y_is_f32) return launch_fwd<true>(g, w_fwd, bias, y, p->Cout, 0, nullptr, nullptr, p->Cout, (hipStream_t)stream);
-  return launch_fwd<false>(g, w_fwd, bias, y, p->Cout, 0, stat_sum, stat_sq, p->Cout, (hipStream_t)stream);
+  if (y_is_f32) return launch_fwd<true>(g, w_fwd, bias, y, p->Cout, 0, Epi{}, p->Cout, (hipStream_t)stream);
+  return launch_fwd<false>(g, w_fwd, bias, y, p->Cout, 0, Epi{stat_sum, stat_sq, {}}, p->Cout, (hipStream_t)stream);
 }
 
-extern "C" int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
-                                 void* stream) {
+namespace {
+// conv-transpose as a forward gather over dy with flipped taps: src = (row - (R-1-pad) + tap') / stride
+int dgrad_gather(const yolo_conv_problem* p, const void* dy, Gather* gp) {
   int rc = check_problem(p);
   if (rc) return rc;
-  YOLO_CHECK_ARG(dy && w_dgrad && dx, "null pointer");
   YOLO_CHECK_ARG(p->Cin % 64 == 0, "dgrad needs Cin % 64 == 0");
   YOLO_CHECK_ARG(ilog2_exact(p->Cout / 8) >= 0, "dgrad needs Cout/8 to be a power of two");
-  // conv-transpose as a forward gather over dy with flipped taps: src = (row - (R-1-pad) + tap') / stride
-  Gather g;
+  Gather& g = *gp;
   g.src0 = nullptr; g.src1 = (const bf16_t*)dy;
   g.Hs = p->Ho; g.Ws = p->Wo; g.C0 = 0; g.C1 = p->Cout;
   g.lgC8 = ilog2_exact(p->Cout / 8);
@@ -1431,7 +1536,49 @@ extern "C" int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, con
     g.M = p->N * g.rowd[0].size * g.cold[0].size;        // the largest class: tile choice and grid size
     g.den = 1;
   }
-  return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate, nullptr, nullptr, p->Cin, (hipStream_t)stream);
+  return YOLO_OK;
+}
+}  // namespace
+
+extern "C" int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                                 void* stream) {
+  YOLO_CHECK_ARG(dy && w_dgrad && dx, "null pointer");
+  Gather g;
+  int rc = dgrad_gather(p, dy, &g);
+  if (rc) return rc;
+  return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate, Epi{}, p->Cin, (hipStream_t)stream);
+}
+
+// rows of the [rows][3][Cin] partial-sum buffer yolo_conv2d_dgrad_bn fills (one per pixel tile, x 4 parity classes on the stride-2 path);
+// rows a launch does not write (classes smaller than the grid) must stay zero: allocate the buffer zeroed, nothing else writes it
+extern "C" int yolo_conv2d_dgrad_bn_rows(const yolo_conv_problem* p) {
+  Gather g;
+  static const char dummy = 0;
+  if (!p || dgrad_gather(p, &dummy, &g)) return YOLO_ERR_INVALID_ARG;
+  if ((size_t)p->N * p->H * p->W * p->Cin >= (1ull << 31)) return YOLO_ERR_INVALID_ARG;     // 32-bit element offsets in the epilogue
+  return (g.s2 ? 4 : 1) * stat_rows_for(g, p->Cin);
+}
+
+// Data gradient whose output is dL/d(out) of a BatchNorm(+ReLU)(+residual / shortcut BN) unit, with that unit's backward REDUCE in the
+// epilogue (see BnEpi): dx receives the masked gradient g (relu_mask: the unit's sign bytes from yolo_bn_act_fwd_mask, or null for a
+// linear unit), partial[rows][3][Cin] the tile sums of g, g xhat(y, mean, rstd) and -- if y2 is given -- g xhat(y2, mean2, rstd2).
+// yolo_bn_bwd_finalize over `partial` and yolo_bn_act_bwd_apply with relu = 0 on dx complete the unit's backward pass.
+extern "C" int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                                    const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2,
+                                    const float* mean2, const float* rstd2, float* partial, void* stream) {
+  YOLO_CHECK_ARG(dy && w_dgrad && dx, "null pointer");
+  YOLO_CHECK_ARG(y && mean && rstd && partial, "the fused reduce needs y, mean, rstd and partial");
+  YOLO_CHECK_ARG(!y2 || (mean2 && rstd2), "y2 needs mean2 and rstd2");
+  YOLO_CHECK_ARG((size_t)p->N * p->H * p->W * p->Cin < (1ull << 31), "the fused reduce addresses dx with 32-bit element offsets");
+  Gather g;
+  int rc = dgrad_gather(p, dy, &g);
+  if (rc) return rc;
+  Epi e = {};
+  e.bn.mask = (const uint8_t*)relu_mask;
+  e.bn.y = (const bf16_t*)y; e.bn.mean = mean; e.bn.rstd = rstd;
+  e.bn.y2 = (const bf16_t*)y2; e.bn.mean2 = mean2; e.bn.rstd2 = rstd2;
+  e.bn.partial = partial;
+  return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate, e, p->Cin, (hipStream_t)stream);
 }
 
 namespace {

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_grouped_kernel(const flo
 __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const bf16_t* __restrict__ res,
                                                                 const float* __restrict__ scale2, const float* __restrict__ shift2,
-                                                                bf16_t* __restrict__ out, size_t nchunks, int C, int relu) {
+                                                                bf16_t* __restrict__ out, size_t nchunks, int C, int relu,
+                                                                uint8_t* __restrict__ mask) {
   const int CV = C >> 3;
   for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_THREADS) {
     const int c = (int)(i % CV) * 8;
@@ -229,6 +230,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __
       for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
     if (relu) {
+      if (mask) {        // ReLU mask, one byte per 8-channel chunk (bit j = channel j is positive): the backward pass reads this instead of `out`
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m |= (v[j] > 0.f ? 1u : 0u) << j;
+        mask[i] = (uint8_t)m;
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
     }
@@ -290,7 +297,11 @@ struct PlainGrad {
   const bf16_t* dout; const bf16_t* out; int relu; int C;
   __device__ __forceinline__ void load(size_t row, int cv, float (&g)[8]) const {
     unpack_bf8(ld16(dout + row * C + cv * 8), g);
-    if (relu) {
+    if (relu == 2) {           // `out` is the forward pass's byte mask [rows][C / 8]
+      const unsigned m = reinterpret_cast<const uint8_t*>(out)[row * (size_t)(C >> 3) + cv];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
+    } else if (relu) {
       float o[8];
       unpack_bf8(ld16(out + row * C + cv * 8), o);
 #pragma unroll
@@ -775,7 +786,14 @@ __global__ __launch_bounds__(FB_THREADS) void bn_bwd_fused_kernel(FusedBwdArgs a
     gk[k] = make_uint4(0u, 0u, 0u, 0u);
     if (i < a.total) {
       uint4 d = ld16(a.dout + i * 8);
-      if (a.relu) {   // g = dout where out > 0 (bf16 sign / zero test on the packed halves)
+      if (a.relu == 2) {   // `out` is the forward pass's byte mask: bit j = channel j of the chunk was positive
+        const unsigned m = reinterpret_cast<const uint8_t*>(a.out)[i];
+        unsigned dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          dw[q] = (((m >> (2 * q)) & 1u) ? (dw[q] & 0xffffu) : 0u) | (((m >> (2 * q + 1)) & 1u) ? (dw[q] & 0xffff0000u) : 0u);
+        d = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+      } else if (a.relu) {   // g = dout where out > 0 (bf16 sign / zero test on the packed halves)
         const uint4 o = ld16(a.out + i * 8);
         const unsigned ow[4] = {o.x, o.y, o.z, o.w};
         unsigned dw[4] = {d.x, d.y, d.z, d.w};
@@ -1096,7 +1114,19 @@ extern "C" int yolo_bn_act_fwd(const void* y, const float* scale, const float* s
   YOLO_CHECK_ARG(!res_scale || res, "res_scale needs res");
   const size_t nch = (size_t)M * (C / 8);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, scale, shift,
-                     (const bf16_t*)res, res_scale, res_shift, (bf16_t*)out, nch, C, relu);
+                     (const bf16_t*)res, res_scale, res_shift, (bf16_t*)out, nch, C, relu, (uint8_t*)nullptr);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_act_fwd_mask(const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+                                    const float* res_shift, void* out, uint8_t* relu_mask, int64_t M, int C, void* stream) {
+  YOLO_CHECK_ARG(y && out && relu_mask && M > 0 && C > 0 && C % 8 == 0, "bad argument");
+  YOLO_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (res_scale == nullptr) == (res_shift == nullptr), "scale/shift pairs");
+  YOLO_CHECK_ARG(!res_scale || res, "res_scale needs res");
+  const size_t nch = (size_t)M * (C / 8);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, scale, shift,
+                     (const bf16_t*)res, res_scale, res_shift, (bf16_t*)out, nch, C, 1, relu_mask);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

@@ -12,6 +12,7 @@ slots are padded to 256 elements); detection-conv outputs padded to 64*2^k chann
 """
 import collections
 import math
+import os
 import numpy as np
 import torch
 from . import ops, backend
@@ -169,6 +170,7 @@ class Val(object):
         self.buf = None
         self.grad = None
         self.grad_init = False
+        self.grad_writers = []          # backward ops that write / accumulate into .grad, in backward order (plan_backward)
         self.needs_grad = True
         self.cached = None
 
@@ -185,6 +187,11 @@ class Graph(object):
         self.tape = []
         self._repack_event = None
         self.fused_bn_bwd = True         # single-launch BatchNorm backward where the tensor fits (ops.bn_act_bwd_fused)
+        # BN+ReLU units leave a byte mask of the activation's sign for the backward pass (decided before finalize; YOLO_RELU_MASK=0 for A/B runs)
+        self.relu_mask = os.environ.get('YOLO_RELU_MASK', '1') != '0'
+        # BatchNorm-backward reduce in the epilogue of the data-gradient convolution that completes the unit's output gradient
+        # (ApplyOp.plan_fusion; YOLO_DGRAD_BN=0 for A/B runs): no reduce pass, no grid barrier
+        self.dgrad_bn = os.environ.get('YOLO_DGRAD_BN', '1') != '0'
         self.vals = []
         self.bns = []            # every keras BatchNormalization (for checkpoints)
         self.bn_groups = []      # allocation units: a BNState or a MultiBN
@@ -427,6 +434,10 @@ class Graph(object):
         for op in reversed(self.tape):
             op.plan_backward()
             self.bwd.append(op.backward)
+        if self.dgrad_bn:
+            for op in self.tape:
+                if isinstance(op, ApplyOp):
+                    op.plan_fusion()
         # gradient buckets for data-parallel overlap, by backbone stage (parameters are laid out in creation order, backward runs in reverse):
         #   [first stride-32 conv, n)   module512 + the three heads, ~70 % of the parameters: complete ~40 % into the backward pass
         #   [first stride-8 conv, that) the stride-8 / stride-16 stages
@@ -639,6 +650,7 @@ class ConvOp(object):
     def plan_backward(self):
         y = self.y
         self.acc = []
+        self.bn_epi = None          # set by ApplyOp.plan_fusion: this data gradient completes a BatchNorm unit's output gradient
         if not self.needs_dgrad():
             return
         x = y.x
@@ -647,12 +659,15 @@ class ConvOp(object):
             a, b = x.a.src, x.b
             self.acc = [a.grad_init, b.grad_init]
             a.grad_init = b.grad_init = True
+            a.grad_writers.append(('cat', self))
+            b.grad_writers.append(('cat', self))
             import copy
             self.pd = copy.copy(y.p)
             self.pd.C0 = 0
         else:
             self.acc = [x.grad_init]
             x.grad_init = True
+            x.grad_writers.append(self)
 
     def _wgrad(self):
         y = self.y
@@ -676,7 +691,7 @@ class ConvOp(object):
             N, H, W, _ = x.shape
             ops.upcat_split_bwd(self.dcat, a.grad, self.acc[0], b.grad, self.acc[1], N, H, W, a.shape[3], b.shape[3])
         else:
-            ops.conv2d_dgrad(y.p, y.dy, self.w_dg, x.grad, accumulate=self.acc[0])
+            ops.conv2d_dgrad(y.p, y.dy, self.w_dg, x.grad, accumulate=self.acc[0], bn=self.bn_epi)
 
 
 class MixConvOp(object):
@@ -709,6 +724,7 @@ class MixConvOp(object):
         x = self.y.x
         self.acc = x.grad_init
         x.grad_init = True
+        x.grad_writers.append(self)
 
     def backward(self):
         y = self.y
@@ -739,6 +755,8 @@ class ApplyOp(object):
         out.grad = out.grad_cell['t']
         C = out.shape[3]
         self.C, self.M = C, out.M
+        # ReLU sign bits of the output, one byte per 8-channel chunk: the backward kernels read this instead of the activation (relu code 2)
+        self.mask = torch.zeros(self.M * (C // 8), dtype=torch.uint8, device=g.dev) if (self.relu and g.relu_mask) else None
         self.P = ops.reduce_rows(self.M, C)
         self.partial = torch.zeros(self.P, 3, C, device=g.dev)
         self.pflat = self.partial.view(-1)
@@ -767,7 +785,7 @@ class ApplyOp(object):
             kw['res'] = self.o_src.buf
             if self.o_bn is not None:
                 kw['res_scale'], kw['res_shift'] = self.o_bn.scale, self.o_bn.shift
-        ops.bn_act_fwd(self.m_src.buf, sc, sh, self.out.buf, self.M, self.C, self.relu, **kw)
+        ops.bn_act_fwd(self.m_src.buf, sc, sh, self.out.buf, self.M, self.C, self.relu, mask=self.mask, **kw)
 
     def plan_backward(self):
         m = self.m_src
@@ -776,17 +794,53 @@ class ApplyOp(object):
         else:
             self.m_dst, self.m_acc = 'grad', m.grad_init
             m.grad_init = True
+            m.grad_writers.append(self)
         o = self.o_src
         self.o_acc = False
         if o is not None and o.kind == 'act':
             self.o_acc = o.grad_init
             o.grad_init = True
+            o.grad_writers.append(self)
+        self.producer = None
+
+    def _reduce_operands(self):
+        """(y1, bn1, y2, bn2) of the backward reduction: quantity 1 belongs to the main BN if there is one, else to the shortcut BN"""
+        m, o, mb, ob = self.m_src, self.o_src, self.m_bn, self.o_bn
+        y1, b1 = (m, mb) if mb is not None else (o, ob)
+        y2, b2 = (o, ob) if (mb is not None and ob is not None) else (None, None)
+        return y1, b1, y2, b2
+
+    def plan_fusion(self):
+        """if the LAST writer of this unit's output gradient is a plain data-gradient convolution, that launch takes over the ReLU masking
+        and the reduce of this unit's backward pass (ops.conv2d_dgrad(bn=...)): backward() is then finalize + apply on the masked gradient"""
+        w = self.out.grad_writers
+        if not w or not isinstance(w[-1], ConvOp) or w[-1].y.x is not self.out or (self.m_bn is None and self.o_bn is None):
+            return
+        conv = w[-1]
+        rows = ops.conv2d_dgrad_bn_rows(conv.y.p)
+        if rows <= 0:
+            return
+        y1, b1, y2, b2 = self._reduce_operands()
+        self.frows = rows
+        self.fpartial = torch.zeros(rows, 3, self.C, device=self.g.dev)     # rows a launch does not write stay zero
+        conv.bn_epi = dict(mask=self.mask, y=y1.buf, mean=b1.mean, rstd=b1.rstd, partial=self.fpartial)
+        if b2 is not None:
+            conv.bn_epi.update(y2=y2.buf, mean2=b2.mean, rstd2=b2.rstd)
+        self.producer = conv
 
     def backward(self):
         out, m, o = self.out, self.m_src, self.o_src
         mb, ob = self.m_bn, self.o_bn
+        sign, relu = (self.mask, 2) if self.mask is not None else (out.buf, self.relu)      # where the ReLU mask comes from
         grouped = mb is not None and len(mb.parts) > 1
-        if self.g.fused_bn_bwd and mb is not None and (ob is None or len(ob.parts) == 1) and \
+        if self.producer is not None:
+            # out.grad already holds the masked gradient and self.fpartial its tile sums (left by the producer's epilogue)
+            y1, b1, y2, b2 = self._reduce_operands()
+            b1.bwd_finalize(self.fpartial.view(-1), self.frows, self.C, 1, self.M)
+            if b2 is not None:
+                b2.bwd_finalize(self.fpartial.view(-1), self.frows, self.C, 2, self.M)
+            sign, relu = None, 0
+        elif self.g.fused_bn_bwd and mb is not None and (ob is None or len(ob.parts) == 1) and \
                 (not grouped or (mb.parts[0][1] == 0 and mb._bounds()[-1] == mb.C)):
             kw = {}
             if o is not None:
@@ -799,15 +853,13 @@ class ApplyOp(object):
                 dbs = [b.v_dbeta for b, _ in mb.parts]
             else:
                 dgs, dbs = mb.v_dgamma, mb.v_dbeta
-            if ops.bn_act_bwd_fused(out.grad, out.buf, self.relu, self.M, self.C, m.buf, mb.scale, mb.mean, mb.rstd, dgs,
+            if ops.bn_act_bwd_fused(out.grad, sign, relu, self.M, self.C, m.buf, mb.scale, mb.mean, mb.rstd, dgs,
                                     dbs, m.dy if self.m_dst == 'dy' else m.grad, self.g.bn_ws, self.g.bn_sync,
                                     acc_dy=self.m_acc, **kw):
                 return
-        if mb is not None or ob is not None:
-            # quantity 1 of the reduction belongs to the main BN if there is one, else to the shortcut BN
-            y1, b1 = (m, mb) if mb is not None else (o, ob)
-            y2, b2 = (o, ob) if (mb is not None and ob is not None) else (None, None)
-            ops.bn_act_bwd_reduce(out.grad, out.buf, self.relu, y1.buf, b1.mean, b1.rstd, self.M, self.C, self.partial,
+        if self.producer is None and (mb is not None or ob is not None):
+            y1, b1, y2, b2 = self._reduce_operands()
+            ops.bn_act_bwd_reduce(out.grad, sign, relu, y1.buf, b1.mean, b1.rstd, self.M, self.C, self.partial,
                                   y2=None if y2 is None else y2.buf, mean2=None if b2 is None else b2.mean,
                                   rstd2=None if b2 is None else b2.rstd)
             b1.bwd_finalize(self.pflat, self.P, self.C, 1, self.M)
@@ -823,7 +875,7 @@ class ApplyOp(object):
                 kw.update(y2=o.buf, a2=ob.scale, mean2=ob.mean, rstd2=ob.rstd, k1b=ob.k1, k2b=ob.k2, dy2=o.dy)
             else:
                 kw.update(dres=o.grad, acc_dres=self.o_acc)
-        ops.bn_act_bwd_apply(out.grad, out.buf, self.relu, self.M, self.C, **kw)
+        ops.bn_act_bwd_apply(out.grad, sign, relu, self.M, self.C, **kw)
 
 
 class PoolOp(object):

@@ -57,8 +57,20 @@ def conv2d_fwd(p, src1, w_fwd, y, src0=None, bias=None, stat_sum=None, stat_sq=N
                                       1 if y.dtype == torch.float32 else 0, _p(stat_sum), _p(stat_sq), _stream()), 'yolo_conv2d_fwd')
 
 
-def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False):
-    check(_lib.load().yolo_conv2d_dgrad(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _stream()), 'yolo_conv2d_dgrad')
+def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False, bn=None):
+    """``bn`` = dict(mask, y, mean, rstd, partial[, y2, mean2, rstd2]): dx is the output gradient of a BatchNorm unit -- leave the masked
+    gradient in dx and the unit's backward partial sums in ``partial`` (yolo_conv2d_dgrad_bn)"""
+    if bn is None:
+        check(_lib.load().yolo_conv2d_dgrad(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _stream()), 'yolo_conv2d_dgrad')
+        return
+    check(_lib.load().yolo_conv2d_dgrad_bn(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _p(bn.get('mask')), _p(bn['y']),
+                                           _p(bn['mean']), _p(bn['rstd']), _p(bn.get('y2')), _p(bn.get('mean2')), _p(bn.get('rstd2')),
+                                           _p(bn['partial']), _stream()), 'yolo_conv2d_dgrad_bn')
+
+
+def conv2d_dgrad_bn_rows(p):
+    """rows of the [rows][3][Cin] partial buffer of conv2d_dgrad(bn=...); -1 if the problem cannot take the fused form"""
+    return int(_lib.load().yolo_conv2d_dgrad_bn_rows(C.byref(p)))
 
 
 def conv2d_wgrad(p, src1, dy, dw, src0=None, split_k=0):
@@ -145,7 +157,12 @@ def bn_bwd_finalize_grouped(partial, P, Cc, which, count, split, dgammas, dbetas
                                                    _ptr_array(dbetas), _p(k1), _p(k2), _stream()), 'yolo_bn_bwd_finalize_grouped')
 
 
-def bn_act_fwd(y, scale, shift, out, M, Cc, relu, res=None, res_scale=None, res_shift=None):
+def bn_act_fwd(y, scale, shift, out, M, Cc, relu, res=None, res_scale=None, res_shift=None, mask=None):
+    """``mask`` (uint8 [M * C / 8], ReLU only): also leave the activation's sign bits for the backward pass (relu = 2 there)"""
+    if mask is not None and relu:
+        check(_lib.load().yolo_bn_act_fwd_mask(_p(y), _p(scale), _p(shift), _p(res), _p(res_scale), _p(res_shift), _p(out), _p(mask), M, Cc,
+                                               _stream()), 'yolo_bn_act_fwd_mask')
+        return
     check(_lib.load().yolo_bn_act_fwd(_p(y), _p(scale), _p(shift), _p(res), _p(res_scale), _p(res_shift), _p(out), M, Cc, int(relu),
                                       _stream()), 'yolo_bn_act_fwd')
 
