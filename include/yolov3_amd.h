@@ -119,7 +119,10 @@ int yolo_conv2d_wgrad_reduce(const yolo_conv_problem* p, const void* src0, const
  * Cout*R*S*Cin floats; with one split the kernel stores straight into dw and `slabs` is not touched), and ONE summing launch per gradient
  * bucket for all its layers once the bucket's backward pass is complete (the gradient exchange / optimizer of the bucket follow it).
  * table_dev: device int64 [nentries][5] = {first float4 of the layer's dw in `grads`, first float4 of its slabs in `arena`, float4s per
- * slab, number of slabs, first workgroup}; total_blocks = sum of ceil(float4s / 64).  Same summation order as yolo_conv2d_wgrad_reduce. */
+ * slab, number of slabs, first workgroup}; a workgroup covers 64 float4s of a layer, or 16 when the layer has YOLO_REDUCE_WIDE_SLABS or more
+ * slabs (16 slab lanes instead of 4): total_blocks = sum of ceil(float4s / 64 or 16).  Below that threshold: the summation order of
+ * yolo_conv2d_wgrad_reduce. */
+#define YOLO_REDUCE_WIDE_SLABS 64
 int yolo_conv2d_wgrad_splits(const yolo_conv_problem* p);
 int yolo_conv2d_wgrad_slabs(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw, float* slabs,
                             size_t slab_bytes, void* stream);
@@ -209,6 +212,17 @@ int yolo_bn_pool_bwd_reduce(const void* dout, const void* out, const uint8_t* ar
 int yolo_bn_pool_bwd_apply(const void* dout, const void* out, const uint8_t* argmax, int relu, const void* y, const float* a1,
                            const float* mean, const float* rstd, const float* k1, const float* k2, void* dy, int N, int H, int W, int C,
                            int Ho, int Wo, int pad_t, int pad_l, void* stream);
+/* The stem's whole backward pass behind the reduce / finalize pair above, WITHOUT materialising the pre-pool gradient: un-pooling of
+ * dout (ReLU-masked by `out` if relu), BatchNorm apply (a1 == NULL: no BatchNorm, dy = un-pooled gradient) and the stem convolution's
+ * weight gradient in one persistent kernel (csrc/stem_bwd.hip).  The stem convolution p (RGB padded to 8 channels -> 64, 3x3, stride 2,
+ * even size) has no data gradient, so nothing else reads dy.  slabs: yolo_stem_pool_bwd_slabs(...) float32 slabs of [64][3][3][8]
+ * (0 = this stem is not covered: use yolo_bn_pool_bwd_apply + yolo_conv2d_wgrad_slabs), summed by yolo_wgrad_reduce_batched like any
+ * other layer's.  x: the packed image [N][p->H][p->W][8]; y: the stem convolution's output [N][p->Ho][p->Wo][64]; dout / out / argmax:
+ * the pooled map [N][Ho][Wo][64].  Replaces autodiff of /root/reference/backbone/resnet18.py:59-61, resnet18_v2.py:61-62, mixnet18.py:72. */
+int yolo_stem_pool_bwd_slabs(const yolo_conv_problem* p, int pooled_channels, int Ho, int Wo, int pad_t, int pad_l);
+int yolo_stem_pool_bwd_wgrad(const yolo_conv_problem* p, const void* x, const void* dout, const void* out, const uint8_t* argmax, int relu,
+                             const void* y, const float* a1, const float* mean, const float* rstd, const float* k1, const float* k2,
+                             int Ho, int Wo, int pad_t, int pad_l, float* slabs, size_t slab_bytes, void* stream);
 /* gradient of concat(upsample2x(a), b): da[N,H/2,W/2,C0] (=|+=) 2x2 sums of dcat[..., :C0]; db[N,H,W,C1] (=|+=) dcat[..., C0:]
  * (/root/reference/yolov3/yolov3_detector.py:115-116,140-141) */
 int yolo_upcat_split_bwd(const void* dcat, void* da, int acc_a, void* db, int acc_b, int N, int H, int W, int C0, int C1, void* stream);

@@ -72,7 +72,7 @@ def mocked_kernels(monkeypatch):
         fn = getattr(ops, name)
         if callable(fn) and getattr(fn, '__module__', None) == ops.__name__ and name not in (
                 'same_pad', 'conv_problem', 'mix_problem', 'pad_channels', 'make_loss_config', 'conv2d_stat_rows', 'reduce_rows', 'radam_l2_blocks',
-                'loss_workspace_bytes', 'check', '_p', '_stream', 'conv2d_wgrad_workspace_bytes', 'conv2d_wgrad_splits', 'conv2d_dgrad_bn_rows', 'bn_bwd_fused_workspace_floats', 'bn_bwd_fused_sync_words', 'dwconv_mix_wgrad_workspace_bytes'):
+                'loss_workspace_bytes', 'check', '_p', '_stream', 'conv2d_wgrad_workspace_bytes', 'conv2d_wgrad_splits', 'conv2d_dgrad_bn_rows', 'stem_pool_bwd_slabs', 'reduce_blocks', 'bn_bwd_fused_workspace_floats', 'bn_bwd_fused_sync_words', 'dwconv_mix_wgrad_workspace_bytes'):
             monkeypatch.setattr(ops, name, (lambda n: (lambda *a, **k: calls.append(n)))(name))
     monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
     monkeypatch.setattr(torch.cuda, 'current_device', lambda: 0)
@@ -111,7 +111,9 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
     m._fwd_bwd()
     m._update()
     c = collections.Counter(mocked_kernels)
-    assert c['conv2d_fwd'] == n_conv and c['conv2d_wgrad_slabs'] == n_conv and c['conv2d_dgrad'] == n_conv - 1
+    # (the stem's weight gradient comes out of the fused stem backward kernel together with the un-pooling and the BatchNorm apply)
+    assert c['conv2d_fwd'] == n_conv and c['conv2d_wgrad_slabs'] == n_conv - 1 and c['conv2d_dgrad'] == n_conv - 1
+    assert c['stem_pool_bwd_wgrad'] == 1 and c['bn_pool_bwd_apply'] == 0
     assert 1 <= c['wgrad_reduce_batched'] <= 3 and c['conv2d_wgrad_reduce'] == 0        # one slab-summing launch per gradient bucket
     assert c['loss_fwd_bwd'] == 1 and c['radam_l2_step'] == 1 and c['radam_schedule'] == 1 and c['upcat_split_bwd'] == 2
     assert c['bn_finalize'] + 4 * c['bn_finalize_grouped'] == n_bn      # MixNet: one grouped launch per 4 group BatchNorms

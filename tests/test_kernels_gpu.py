@@ -692,6 +692,57 @@ def test_pool_bwd_scatter_equals_gather(dev, shape):
     assert torch.equal(res[0], res[1])
 
 
+@pytest.mark.parametrize('shape,bn', [((2, 64, 96), True), ((3, 40, 56), True), ((1, 416, 416), True), ((2, 72, 40), False),
+                                      ((1, 16, 32), True)], ids=str)
+def test_stem_backward_in_one_kernel(dev, shape, bn):
+    """stem_pool_bwd_wgrad (un-pool + BatchNorm apply + stem weight gradient, pre-pool gradient never written) against the two-kernel
+    path on the same inputs: bn_pool_bwd_apply -> dy (16-bit) -> conv2d_wgrad.  Same products of the same rounded dy, float32 sums in a
+    different order.  Ragged tiles (40 x 56 input: 20 x 28 pre-pool map), one tile only (a single slab), and the no-BatchNorm stem of
+    ResNet18-v2 (resnet18_v2.py:61-62: dy = the un-pooled gradient)"""
+    from yolov3_tensorflow_amd import ops
+    from oracle.nets import same_pad
+    N, Hi, Wi = shape
+    g = torch.Generator().manual_seed(Hi * 7 + Wi)
+    p = ops.conv_problem(N, Hi, Wi, 8, 64, 3, 2, 'same')
+    H, W, Cc = p.Ho, p.Wo, 64
+    x = torch.zeros(N, Hi, Wi, 8)
+    x[..., :3] = torch.rand(N, Hi, Wi, 3, generator=g)
+    x = bf(x).to(dev)
+    y = bf(torch.randn(N, H, W, Cc, generator=g)).to(dev)
+    (pt, _), (pl, _) = same_pad(H, 3, 2), same_pad(W, 3, 2)
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    sc = (torch.rand(Cc, generator=g) - 0.3).to(dev)
+    sh, mean, rstd, k1, k2 = [(torch.randn(Cc, generator=g) * s_).to(dev) for s_ in (0.1, 0.2, 1.0, 0.05, 0.05)]
+    out = torch.empty(N, Ho, Wo, Cc, dtype=ACT(), device=dev)
+    arg = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=dev)
+    ops.bn_pool_fwd(y, sc if bn else None, sh if bn else None, out, arg, N, H, W, Cc, Ho, Wo, pt, pl, bn)       # ReLU only on the BN stem
+    dout = bf(torch.randn(N, Ho, Wo, Cc, generator=g)).to(dev)
+    a = (sc, mean, rstd, k1, k2) if bn else (None,) * 5
+    dy = torch.empty(N, H, W, Cc, dtype=ACT(), device=dev)
+    ops.bn_pool_bwd_apply(dout, out, arg, bn, y if bn else None, *a, dy, N, H, W, Cc, Ho, Wo, pt, pl)
+    dw_ref = torch.zeros(64, 3, 3, 8, device=dev)
+    ops.conv2d_wgrad(p, x, dy, dw_ref)
+    n = ops.stem_pool_bwd_slabs(p, Cc, Ho, Wo, pt, pl)
+    tiles = N * -(-H // 8) * -(-W // 16)
+    assert n == min(tiles, 512)
+    slabs = torch.full((n, 64, 3, 3, 8), float('nan'), device=dev)
+    ops.stem_pool_bwd_wgrad(p, x, dout, out, arg, bn, y, *a, Ho, Wo, pt, pl, slabs)
+    torch.cuda.synchronize()
+    got = slabs.double().sum(0)
+    assert torch.isfinite(got).all() and float(got[..., 3:].abs().max()) == 0.0
+    scale = float(dw_ref.abs().max())
+    torch.testing.assert_close(got.float(), dw_ref, rtol=2e-3, atol=2e-4 * max(scale, 1.0))
+    # the bucket's summing launch takes the many-slab form (16 slab lanes) from 64 slabs on
+    if n > 1:
+        grads = torch.zeros(64 * 72, device=dev)
+        n4 = 64 * 72 // 4
+        blocks = ops.reduce_blocks(n4, n)
+        tab = torch.tensor([[0, 0, n4, n, 0]], dtype=torch.int64, device=dev)
+        ops.wgrad_reduce_batched(tab, 1, blocks, slabs.view(-1), grads)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(grads.view(64, 3, 3, 8), got.float(), rtol=1e-5, atol=1e-6 * max(scale, 1.0))
+
+
 @pytest.mark.parametrize('f,N,H,W', [(64, 2, 11, 9), (128, 2, 11, 9), (64, 3, 40, 104), (512, 5, 13, 13), (256, 2, 26, 26), (64, 1, 3, 2)])
 def test_mixconv_fwd_dgrad_wgrad(dev, f, N, H, W):
     """mixed depthwise conv (mixnet18.py:38-45) vs 4 x F.conv2d(groups=C_g) on channel slices: ragged strips, several row tiles per

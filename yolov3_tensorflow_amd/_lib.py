@@ -68,6 +68,8 @@ SIGNATURES = {
     'yolo_conv2d_wgrad_splits': (I, [CP]),
     'yolo_conv2d_wgrad_slabs': (I, [CP, P, P, P, P, P, C.c_size_t, P]),
     'yolo_wgrad_reduce_batched': (I, [P, I, I, P, P, P]),
+    'yolo_stem_pool_bwd_slabs': (I, [CP, I, I, I, I, I]),
+    'yolo_stem_pool_bwd_wgrad': (I, [CP, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, P, C.c_size_t, P]),
     'yolo_repack_dgrad_weights': (I, [P, P, I, I, I, I, P]),
     'yolo_repack_dgrad_weights_batched': (I, [P, P, P, I, I, P]),
     'yolo_reduce_rows': (I, [I, I]),

@@ -1174,33 +1174,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restr
 // become 3.  tab[e] = {first float4 of dW in `grads`, first float4 of the slabs in `arena`, float4s per slab, slabs, first workgroup}.
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const long long* __restrict__ tab, int n, const float4* __restrict__ arena,
                                                                    float4* __restrict__ grads) {
-  __shared__ float4 red[4][64];
+  __shared__ float4 red[256];
   int e = 0;
   for (int k = 1; k < n; ++k) e = ((long long)blockIdx.x >= tab[k * 5 + 4]) ? k : e;      // n <= a few dozen, uniform: scalar loads
   const long long dst4 = tab[e * 5], src4 = tab[e * 5 + 1], n4 = tab[e * 5 + 2];
   const int nslab = (int)tab[e * 5 + 3];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long long i = ((long long)blockIdx.x - tab[e * 5 + 4]) * 64 + col;
+  // a workgroup covers 64 float4 columns with 4 slab lanes, or -- layers with many slabs (YOLO_REDUCE_WIDE_SLABS and more: small layers
+  // split over hundreds of pixel ranges, the stem's per-workgroup slabs) -- 16 columns with 16 lanes: 4x the loads in flight per column
+  const bool wide = nslab >= YOLO_REDUCE_WIDE_SLABS;
+  const int ncol = wide ? 16 : 64, nl = wide ? 16 : 4;
+  const int col = threadIdx.x % ncol, grp = threadIdx.x / ncol;
+  const long long i = ((long long)blockIdx.x - tab[e * 5 + 4]) * ncol + col;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
     const float4* p = arena + src4 + i;
     int z = grp;
-    for (; z + 12 < nslab; z += 16) {
-      const float4 a = p[(size_t)z * n4], b = p[(size_t)(z + 4) * n4], c = p[(size_t)(z + 8) * n4], d = p[(size_t)(z + 12) * n4];
+    for (; z + 3 * nl < nslab; z += 4 * nl) {
+      const float4 a = p[(size_t)z * n4], b = p[(size_t)(z + nl) * n4], c = p[(size_t)(z + 2 * nl) * n4], d = p[(size_t)(z + 3 * nl) * n4];
       s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
       s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
     }
-    for (; z < nslab; z += 4) {
+    for (; z < nslab; z += nl) {
       const float4 a = p[(size_t)z * n4];
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
   }
-  red[grp][col] = s;
+  red[grp * ncol + col] = s;
   __syncthreads();
   if (grp == 0 && i < n4) {
-    float4 r = red[0][col];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) { r.x += red[k][col].x; r.y += red[k][col].y; r.z += red[k][col].z; r.w += red[k][col].w; }
+    float4 r = red[col];
+    for (int k = 1; k < nl; ++k) { const float4 o = red[k * ncol + col]; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
     grads[dst4 + i] = r;
   }
 }

@@ -192,6 +192,9 @@ class Graph(object):
         # BatchNorm-backward reduce in the epilogue of the data-gradient convolution that completes the unit's output gradient
         # (ApplyOp.plan_fusion; YOLO_DGRAD_BN=0 for A/B runs): no reduce pass, no grid barrier
         self.dgrad_bn = os.environ.get('YOLO_DGRAD_BN', '1') != '0'
+        # the stem's backward pass (un-pool + BatchNorm apply + weight gradient) as one kernel that never writes the pre-pool gradient
+        # (PoolOp.plan_fusion; YOLO_STEM_BWD=0 for A/B runs)
+        self.stem_bwd = os.environ.get('YOLO_STEM_BWD', '1') != '0'
         self.vals = []
         self.bns = []            # every keras BatchNormalization (for checkpoints)
         self.bn_groups = []      # allocation units: a BNState or a MultiBN
@@ -413,8 +416,11 @@ class Graph(object):
         # (the depthwise weight gradients keep their own shared workspace: they run back to back on one stream and sum right away)
         n_slab = 0
         for op in self.tape:
+            if isinstance(op, PoolOp) and self.stem_bwd:
+                op.plan_fusion()
+        for op in self.tape:
             if isinstance(op, ConvOp):
-                op.splits = ops.conv2d_wgrad_splits(op.y.p)
+                op.splits = op.fused_slabs or ops.conv2d_wgrad_splits(op.y.p)
                 op.slab_off = n_slab
                 if op.splits > 1:
                     n_slab += op.splits * op.y.wp.numel
@@ -470,7 +476,7 @@ class Graph(object):
                 if isinstance(op, ConvOp) and op.splits > 1 and lo <= op.y.wp.offset < hi_:
                     n4 = op.y.wp.numel // 4
                     rows.append([op.y.wp.offset // 4, op.slab_off // 4, n4, op.splits, blocks])
-                    blocks += (n4 + 63) // 64
+                    blocks += ops.reduce_blocks(n4, op.splits)
             self.reduce_tables[(lo, hi_)] = (torch.tensor(rows, dtype=torch.int64, device=dev) if rows else None, len(rows), blocks)
 
     def refresh_dgrad_weights(self):
@@ -605,6 +611,7 @@ class Graph(object):
 class ConvOp(object):
     def __init__(self, g, y):
         self.g, self.y = g, y
+        self.fused_slabs = 0        # > 0: a PoolOp's fused backward kernel writes this convolution's weight-gradient slabs (stem)
 
     def needs_dgrad(self):
         x = self.y.x
@@ -681,7 +688,8 @@ class ConvOp(object):
     def backward(self):
         y = self.y
         p = y.p
-        self.g.on_wgrad_stream(self._wgrad, cost=2e-9 * p.N * p.Ho * p.Wo * p.Cout * p.Cin * p.R * p.S)
+        if not self.fused_slabs:
+            self.g.on_wgrad_stream(self._wgrad, cost=2e-9 * p.N * p.Ho * p.Wo * p.Cout * p.Cin * p.R * p.S)
         if not self.needs_dgrad():
             return
         x = y.x
@@ -886,6 +894,20 @@ class PoolOp(object):
         self.src, self.bn = _branch(v.src)
         if self.src.kind != 'conv':
             raise NotImplementedError('max-pool over a non-conv value')
+        self.conv_op = None
+
+    def plan_fusion(self):
+        """the stem (image -> conv3x3 s2 -> [BN] -> max-pool -> [ReLU]): its convolution has no data gradient, so the pre-pool gradient
+        feeds the weight gradient only -- one kernel does un-pool + BatchNorm apply + weight gradient (ops.stem_pool_bwd_wgrad)"""
+        src = self.src
+        conv = next((op for op in self.g.tape if isinstance(op, ConvOp) and op.y is src), None)
+        if conv is None or conv.needs_dgrad() or src.bp is not None or (self.bn is not None and len(getattr(self.bn, 'parts', [0])) > 1):
+            return
+        out = self.out
+        n = ops.stem_pool_bwd_slabs(src.p, src.shape[3], out.shape[1], out.shape[2], self.v.pt, self.v.pl)
+        if n > 0:
+            conv.fused_slabs = n
+            self.conv_op = conv
 
     def bind(self):
         g, out = self.g, self.out
@@ -916,7 +938,12 @@ class PoolOp(object):
             ops.bn_pool_bwd_reduce(out.grad, out.buf, self.argmax, self.relu, src.buf, bn.mean, bn.rstd, *self.geom, self.partial,
                                    gamma=getattr(bn, 'v_gamma', None), beta=getattr(bn, 'v_beta', None))
             bn.bwd_finalize(self.partial.view(-1), self.P, C, 1, N * H * W)
-            ops.bn_pool_bwd_apply(out.grad, out.buf, self.argmax, self.relu, src.buf, bn.scale, bn.mean, bn.rstd, bn.k1, bn.k2, src.dy,
-                                  *self.geom)
+        a1, mean, rstd, k1, k2 = (bn.scale, bn.mean, bn.rstd, bn.k1, bn.k2) if bn is not None else (None,) * 5
+        conv = self.conv_op
+        if conv is not None:
+            Ho, Wo, pt, pl = self.geom[4:]
+            ops.stem_pool_bwd_wgrad(src.p, conv.src1.buf, out.grad, out.buf, self.argmax, self.relu, src.buf, a1, mean, rstd, k1, k2,
+                                    Ho, Wo, pt, pl, conv.slabs if conv.slabs is not None else conv.dw)      # one tile: straight into dW
         else:
-            ops.bn_pool_bwd_apply(out.grad, out.buf, self.argmax, self.relu, None, None, None, None, None, None, src.dy, *self.geom)
+            ops.bn_pool_bwd_apply(out.grad, out.buf, self.argmax, self.relu, src.buf if bn is not None else None, a1, mean, rstd, k1, k2,
+                                  src.dy, *self.geom)

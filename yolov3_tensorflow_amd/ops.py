@@ -102,6 +102,26 @@ def conv2d_wgrad_slabs(p, src1, dy, dw, slabs, src0=None):
                                               0 if slabs is None else slabs.numel() * slabs.element_size(), _stream()), 'yolo_conv2d_wgrad_slabs')
 
 
+REDUCE_WIDE_SLABS = 64      # YOLO_REDUCE_WIDE_SLABS: layers with this many slabs get 16-column workgroups in wgrad_reduce_batched
+
+
+def reduce_blocks(n4, nslabs):
+    """workgroups of wgrad_reduce_batched for a layer of n4 float4s per slab"""
+    cols = 16 if nslabs >= REDUCE_WIDE_SLABS else 64
+    return (n4 + cols - 1) // cols
+
+
+def stem_pool_bwd_slabs(p, C_pool, Ho, Wo, pt, pl):
+    """slabs the fused stem backward (stem_pool_bwd_wgrad) writes, 0 if this stem is not covered"""
+    return int(_lib.load().yolo_stem_pool_bwd_slabs(C.byref(p), C_pool, Ho, Wo, pt, pl))
+
+
+def stem_pool_bwd_wgrad(p, x, dout, out, argmax, relu, y, a1, mean, rstd, k1, k2, Ho, Wo, pt, pl, slabs):
+    check(_lib.load().yolo_stem_pool_bwd_wgrad(C.byref(p), _p(x), _p(dout), _p(out), _p(argmax), int(relu), _p(y), _p(a1), _p(mean), _p(rstd),
+                                               _p(k1), _p(k2), Ho, Wo, pt, pl, _p(slabs), slabs.numel() * 4, _stream()),
+          'yolo_stem_pool_bwd_wgrad')
+
+
 def wgrad_reduce_batched(table_dev, nentries, total_blocks, arena, grads):
     check(_lib.load().yolo_wgrad_reduce_batched(_p(table_dev), nentries, total_blocks, _p(arena), _p(grads), _stream()), 'yolo_wgrad_reduce_batched')
 
