@@ -5,16 +5,16 @@
 // gradient ONLY.  The two-kernel form wrote it (177 MB at 416^2 / batch 32) and read it back: 151 us (un-pool + BatchNorm apply) + 77 us
 // (implicit-GEMM weight gradient, K = 27) serial at the very end of the step, with nothing left to overlap them.  Here a workgroup owns
 // 8 x 16 pre-pool pixels at a time:
-//   1. the <= 6 x 10 pooled pixels whose windows touch the tile scatter their (ReLU-masked) gradient to the position their arg-max names,
-//      into a float32 LDS tile -- four barrier-separated window classes (dh == 2, dw == 2), disjoint targets within a class: ds_add_f32
-//      without contention, deterministic (same scheme as bn_pool_bwd_apply_scatter_kernel).  This is the expensive step: 88 of the
-//      kernel's 216 us at 416^2 / batch 32 (ablation, tools/probes/stem_bwd_bench.py)
-//   2. BatchNorm apply dy = a (g - k1 - xhat k2) = A g + B y + D (or dy = g without BN), rounded to the 16-bit activation type as the
-//      stored dy was, into a [64 pixel rows][128 columns] LDS image (column = 64 * (tile row >> 2) + channel) laid out for ds_read_b64_tr_b16
+//   1. the <= 6 x 10 pooled pixels whose windows touch the tile are staged in LDS (ReLU-masked gradient + arg-max bytes, 24 B per
+//      8-channel chunk); every pre-pool chunk then GATHERS from the 1..4 windows covering it: g[j] += d[j] where the window's arg-max
+//      byte names this position -- in the window-class order (dh == 2, dw == 2) of bn_pool_bwd_apply_scatter_kernel, so the float32
+//      sums are the same.  (A scatter through ds_add_f32 into a float32 LDS tile, four barrier-separated classes, cost 88 of 216 us.)
+//   2. BatchNorm apply dy = a (g - k1 - xhat k2) = A g + B y + D (or dy = g without BN) in registers, rounded to the 16-bit activation
+//      type as the stored dy was, into a [64 pixel rows][128 columns] LDS image (column = 64 * (tile row >> 2) + channel) laid out for ds_read_b64_tr_b16
 //   3. dW[co][tap * 4 + ch] += sum over the 128 pixels dy[p][co] * x[2h + r][2w + s][ch]: v_mfma_f32_16x16x32 with the pixels as K; wave w
 //      takes pixels 32w .. 32w+31 for all 4 x 3 output tiles.  A (dy^T) comes from the transposed LDS read, B from a 17 x 33 pixel patch
 //      of the packed image (4 channels x 2 bytes per pixel in LDS) gathered with eight 2-byte reads per fragment
-// The grid is persistent (2 workgroups per CU: 54 KB of LDS, ~190 VGPRs); every workgroup keeps its 64 x 48 float32 partial in registers over its tiles and writes
+// The grid is persistent (3 workgroups per CU); every workgroup keeps its 64 x 48 float32 partial in registers over its tiles and writes
 // ONE slab [64][3][3][8]; the gradient bucket's summing launch (yolo_wgrad_reduce_batched) adds the slabs.  No atomics.
 #include "common.h"
 
@@ -28,11 +28,13 @@ constexpr int MAXP = (PR * PC * CV + SB_THREADS - 1) / SB_THREADS;      // poole
 constexpr int MAXQ = TPIX * CV / SB_THREADS;                            // pre-pool chunks per thread (4)
 constexpr int XR = 2 * TH + 1, XC = 2 * TW + 1;          // image patch (pixels)
 constexpr int MAXX = (XR * XC + SB_THREADS - 1) / SB_THREADS;           // patch pixels per thread (3)
-constexpr int GT_BYTES = TPIX * C * 4;                   // float32 gradient tile
+constexpr int NPOOL = PR * PC * CV;                      // staged pooled chunks
+constexpr int SG_BYTES = NPOOL * 16, SA_BYTES = NPOOL * 8;
 constexpr int IMG_BYTES = 64 * 256;                      // dy image for the transposed reads
 constexpr int XP_BYTES = (XR * XC * 8 + 15) / 16 * 16;
 constexpr int CST_BYTES = 3 * C * 4;                     // dy = A g + B y + D per channel (in LDS, not in 24+ loop-invariant registers per thread)
-constexpr int SB_LDS = GT_BYTES + IMG_BYTES + XP_BYTES + CST_BYTES;
+constexpr int SB_LDS = SG_BYTES + SA_BYTES + IMG_BYTES + XP_BYTES + CST_BYTES;
+constexpr int SB_WG_PER_CU = 3;
 
 struct StemBwdArgs {
   const bf16_t* dout; const bf16_t* out; const uint8_t* argmax;   // pooled [N][Ho][Wo][64]; out == null: no ReLU
@@ -62,17 +64,18 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* img, int p0, int col0, i
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
-__global__ __launch_bounds__(SB_THREADS, 2) void stem_pool_bwd_wgrad_kernel(StemBwdArgs a) {
+__global__ __launch_bounds__(SB_THREADS, SB_WG_PER_CU) void stem_pool_bwd_wgrad_kernel(StemBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* gt = reinterpret_cast<float*>(smem);                 // [TPIX][64]
-  char* img = smem + GT_BYTES;
+  uint4* sG = reinterpret_cast<uint4*>(smem);                 // [NPOOL] masked pooled gradient, 8 channels
+  uint2* sA = reinterpret_cast<uint2*>(smem + SG_BYTES);      // [NPOOL] arg-max codes, 8 bytes (0xff: no window here)
+  char* img = smem + SG_BYTES + SA_BYTES;
   char* xp = img + IMG_BYTES;                                 // [XR][XC] x 8 bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* cst = reinterpret_cast<float*>(xp + XP_BYTES);        // [3][64]: A = a, B = -a rstd k2, D = a (mean rstd k2 - k1)
   if (a.a1 && tid < C) {
     const float aa = a.a1[tid], rk = a.rstd[tid] * a.k2[tid];
     cst[tid] = aa; cst[C + tid] = -aa * rk; cst[2 * C + tid] = aa * (a.mean[tid] * rk - a.k1[tid]);
-  }                                                           // (visible after the first tile's barriers)
+  }                                                           // (visible after the first tile's first barrier)
 
   f32x4_t acc[4][3];
 #pragma unroll
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void stem_pool_bwd_wgrad_kernel(Stem
     bval[t] = tap < 9;
     boff[t] = bval[t] ? ((2 * hl_b + r) * XC + 2 * wl_b + s) * 8 + ch * 2 : 0;
   }
+  const int cv = tid % CV, c = cv * 8;                        // SB_THREADS is a multiple of CV: a thread keeps its channel chunk
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int b = tile;
@@ -101,106 +105,92 @@ __global__ __launch_bounds__(SB_THREADS, 2) void stem_pool_bwd_wgrad_kernel(Stem
     const int h0 = th * TH, w0 = tw * TW;
     const int ho0 = max(0, (h0 + a.pt - 1) >> 1), wo0 = max(0, (w0 + a.pl - 1) >> 1);
 
-    // ---- A: zero the gradient tile (the previous tile's apply pass is behind the barrier that preceded its MFMA phase); request everything
-    for (int i = tid; i < TPIX * C / 4; i += SB_THREADS) reinterpret_cast<float4*>(gt)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // per pooled chunk: the masked gradient (packed, 4 registers) and, per channel, 16 bits = LDS float index of the target (13 bits) |
-    // window class << 13, or 0xffff = nothing to add (target in a neighbouring tile, padding position, out of range)
-    uint4 dg[MAXP];
-    unsigned tg[MAXP][4];
+    // ---- A: request everything this tile needs
+    uint4 pg[MAXP], po[MAXP];
+    uint2 pa[MAXP];
 #pragma unroll
     for (int q = 0; q < MAXP; ++q) {
-      const int i = tid + q * SB_THREADS;
-      dg[q] = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tg[q][j] = 0xffffffffu;
-      if (i >= PR * PC * CV) continue;
-      const int cv = i % CV, pp = i / CV;
+      const int i = tid + q * SB_THREADS, pp = i / CV;
       const int ho = ho0 + pp / PC, wo = wo0 + pp % PC;
-      if (ho >= a.Ho || wo >= a.Wo) continue;
-      const size_t o = ((size_t)(n * a.Ho + ho) * a.Wo + wo) * C + cv * 8;
-      uint4 g = ld16g(a.dout + o);
-      const uint2 am = *reinterpret_cast<const uint2*>(a.argmax + o);
-      if (a.out) {
-        const uint4 ov = ld16g(a.out + o);
-        const unsigned ow[4] = {ov.x, ov.y, ov.z, ov.w};
-        unsigned gw[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned lo = ow[k] & 0xffffu, hi = ow[k] >> 16;
-          gw[k] = ((lo != 0u && lo < 0x8000u) ? (gw[k] & 0xffffu) : 0u) | ((hi != 0u && hi < 0x8000u) ? (gw[k] & 0xffff0000u) : 0u);
-        }
-        g = make_uint4(gw[0], gw[1], gw[2], gw[3]);
-      }
-      dg[q] = g;
-      const int hb = 2 * ho - a.pt - h0, wb = 2 * wo - a.pl - w0;     // tile-local position of the window's top-left tap
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int code = (int)((j < 4 ? (am.x >> (8 * j)) : (am.y >> (8 * (j - 4)))) & 0xffu);
-        const int dh = (code * 11) >> 5, dw = code - 3 * dh;          // code = 3 dh + dw, code < 9
-        const int hl = hb + dh, wl = wb + dw;
-        const bool ok = code < 9 && hl >= 0 && hl < TH && wl >= 0 && wl < TW;   // targets outside belong to the neighbouring tile
-        // channel index XOR (wl >> 1): the 8 pooled neighbours a wave handles per channel land in 8 different banks (plain [pix][64]
-        // rows put all of them on the 4 banks of their channel: 16-way conflicts on every add); the apply pass undoes the permutation
-        const unsigned t16 = ok ? (unsigned)((hl * TW + wl) * C + ((cv * 8 + j) ^ (wl >> 1))) | ((unsigned)((dh >> 1) * 2 + (dw >> 1)) << 13)
-                                : 0xffffu;
-        tg[q][j >> 1] = (j & 1) ? ((tg[q][j >> 1] & 0xffffu) | (t16 << 16)) : ((tg[q][j >> 1] & 0xffff0000u) | t16);
+      pg[q] = po[q] = make_uint4(0u, 0u, 0u, 0u);
+      pa[q] = make_uint2(0xffffffffu, 0xffffffffu);
+      if (i < NPOOL && ho < a.Ho && wo < a.Wo) {
+        const size_t o = ((size_t)(n * a.Ho + ho) * a.Wo + wo) * C + c;
+        pg[q] = ld16g(a.dout + o);
+        pa[q] = *reinterpret_cast<const uint2*>(a.argmax + o);
+        if (a.out) po[q] = ld16g(a.out + o);
       }
     }
     uint4 yv[MAXQ];
     bool okq[MAXQ];
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-      const int i = tid + q * SB_THREADS;
-      const int cv = i % CV, pix = i / CV;
+      const int pix = (tid + q * SB_THREADS) / CV;
       const int h = h0 + pix / TW, w = w0 + pix % TW;
       okq[q] = h < a.H && w < a.W;
-      yv[q] = (okq[q] && a.a1) ? ld16g(a.y + ((size_t)(n * a.H + h) * a.W + w) * C + cv * 8) : make_uint4(0u, 0u, 0u, 0u);
+      yv[q] = (okq[q] && a.a1) ? ld16g(a.y + ((size_t)(n * a.H + h) * a.W + w) * C + c) : make_uint4(0u, 0u, 0u, 0u);
     }
     uint2 xv[MAXX];
 #pragma unroll
     for (int q = 0; q < MAXX; ++q) {
       const int i = tid + q * SB_THREADS;
-      const int r = i / XC, c = i - r * XC;
-      const int hi = 2 * h0 + r, wi = 2 * w0 + c;                     // 'same' at stride 2 on an even size pads bottom / right only
+      const int r = i / XC, cc = i - r * XC;
+      const int hi = 2 * h0 + r, wi = 2 * w0 + cc;                    // 'same' at stride 2 on an even size pads bottom / right only
       xv[q] = (i < XR * XC && hi < a.Hi && wi < a.Wi) ? *reinterpret_cast<const uint2*>(a.x + ((size_t)(n * a.Hi + hi) * a.Wi + wi) * 8)
                                                       : make_uint2(0u, 0u);
     }
-    // ---- B: scatter, one window class at a time
+    // ---- B: the pooled chunks, ReLU-masked, into LDS (the previous tile's gather pass is behind its second barrier)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      __syncthreads();                                          // the zero fill / the previous class is complete
+    for (int q = 0; q < MAXP; ++q) {
+      const int i = tid + q * SB_THREADS;
+      if (i < NPOOL) {
+        uint4 g = pg[q];
+        if (a.out) {
+          const unsigned ow[4] = {po[q].x, po[q].y, po[q].z, po[q].w};
+          unsigned gw[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-      for (int q = 0; q < MAXP; ++q) {
-        const unsigned gw[4] = {dg[q].x, dg[q].y, dg[q].z, dg[q].w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const unsigned t16 = (j & 1) ? (tg[q][j >> 1] >> 16) : (tg[q][j >> 1] & 0xffffu);
-          if (t16 != 0xffffu && (t16 >> 13) == (unsigned)k)     // disjoint targets within a class: ds_add_f32, no read-back round trip
-            __hip_atomic_fetch_add(gt + (t16 & 0x1fffu), (j & 1) ? hi2f(gw[j >> 1]) : lo2f(gw[j >> 1]), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int k = 0; k < 4; ++k) {
+            const unsigned lo = ow[k] & 0xffffu, hi = ow[k] >> 16;
+            gw[k] = ((lo != 0u && lo < 0x8000u) ? (gw[k] & 0xffffu) : 0u) | ((hi != 0u && hi < 0x8000u) ? (gw[k] & 0xffff0000u) : 0u);
+          }
+          g = make_uint4(gw[0], gw[1], gw[2], gw[3]);
         }
+        sG[i] = g;
+        sA[i] = pa[q];
       }
     }
-    __syncthreads();
-    // ---- C: BatchNorm apply -> dy image; image patch -> LDS (the previous tile's MFMA phase ended before the scatter barriers)
+    __syncthreads();      // pooled chunks staged; every wave has left the previous tile's MFMA phase (image / patch may be rewritten)
+    // ---- C: gather + BatchNorm apply -> dy image; image patch -> LDS
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-      const int i = tid + q * SB_THREADS;
-      const int cv = i % CV, pix = i / CV, c = cv * 8;
+      const int pix = (tid + q * SB_THREADS) / CV;
+      const int hl = pix / TW, wl = pix % TW;
       float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = 0.f;
       if (okq[q]) {
-        const float4 ga = *reinterpret_cast<const float4*>(gt + pix * C + c), gb = *reinterpret_cast<const float4*>(gt + pix * C + c + 4);
-        float g[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-        const int f = (pix % TW) >> 1;                          // stored at [j ^ f]: three conditional butterfly stages bring it back
+        float g[8];
 #pragma unroll
-        for (int bit = 1; bit < 8; bit <<= 1) {
-          const bool sw = (f & bit) != 0;
+        for (int j = 0; j < 8; ++j) g[j] = 0.f;
+        const int hn = h0 + hl + a.pt, wn = w0 + wl + a.pl;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (!(j & bit)) {
-              const float lo = g[j], hi = g[j | bit];
-              g[j] = sw ? hi : lo;
-              g[j | bit] = sw ? lo : hi;
+        for (int kh = 0; kh < 2; ++kh) {                      // window class along h: dh in {0, 1}, then dh == 2 (even hn only)
+          const int ho = (hn >> 1) - kh, dh = hn - 2 * ho;
+          if ((kh && (hn & 1)) || ho < 0 || ho >= a.Ho) continue;
+#pragma unroll
+          for (int kw = 0; kw < 2; ++kw) {
+            const int wo = (wn >> 1) - kw, dw = wn - 2 * wo;
+            if ((kw && (wn & 1)) || wo < 0 || wo >= a.Wo) continue;
+            const int li = ((ho - ho0) * PC + (wo - wo0)) * CV + cv;
+            const uint2 am = sA[li];
+            const uint4 dv = sG[li];
+            const unsigned code = (unsigned)(dh * 3 + dw);
+            const unsigned dw4[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const unsigned aj = ((j < 4 ? (am.x >> (8 * j)) : (am.y >> (8 * (j - 4)))) & 0xffu);
+              const float d = (j & 1) ? hi2f(dw4[j >> 1]) : lo2f(dw4[j >> 1]);
+              g[j] += aj == code ? d : 0.f;
             }
           }
         }
@@ -208,17 +198,12 @@ __global__ __launch_bounds__(SB_THREADS, 2) void stem_pool_bwd_wgrad_kernel(Stem
           float v[8];
           unpack_bf8(yv[q], v);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            r[j] = cst[c + j] * g[j] + (cst[C + c + j] * v[j] + cst[2 * C + c + j]);
+          for (int j = 0; j < 8; ++j) r[j] = cst[c + j] * g[j] + (cst[C + c + j] * v[j] + cst[2 * C + c + j]);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) r[j] = g[j];
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = 0.f;
       }
-      const int hl = pix / TW, wl = pix % TW;
       const int row = (hl & 3) * 16 + wl, chunk = (hl >> 2) * 8 + cv;
       *reinterpret_cast<uint4*>(img + row * 256 + ((chunk ^ img_f(row)) << 4)) = pack_bf8(r);
     }
@@ -245,7 +230,6 @@ __global__ __launch_bounds__(SB_THREADS, 2) void stem_pool_bwd_wgrad_kernel(Stem
 #pragma unroll
       for (int t = 0; t < 3; ++t) acc[ct][t] = YOLO_MFMA_16x16x32(af, bfrag[t], acc[ct][t]);
     }
-    // (the next tile's zero fill touches gt only; its image / patch writes come after four more barriers)
   }
 
   // ---- the four waves' partials meet in LDS, one wave at a time; then the slab in the device weight layout [co][tap][8]
@@ -280,10 +264,10 @@ inline bool stem_bwd_ok(const yolo_conv_problem* p, int Cpool, int Ho, int Wo, i
 
 inline int stem_bwd_grid(const yolo_conv_problem* p) {
   const int tiles = p->N * ((p->Ho + TH - 1) / TH) * ((p->Wo + TW - 1) / TW);
-  return tiles < 512 ? tiles : 512;                            // 2 workgroups (54 KB of LDS, ~190 VGPRs) per CU
+  return tiles < 256 * SB_WG_PER_CU ? tiles : 256 * SB_WG_PER_CU;
 }
 
-static_assert(2 * SB_LDS <= 160 * 1024, "two workgroups per CU");
+static_assert(SB_WG_PER_CU * (SB_LDS + 1024) <= 160 * 1024, "workgroups per CU (LDS, with allocation granularity)");
 
 }  // namespace
 
