@@ -103,7 +103,10 @@ def kernel_rooflines(model, steps, overlap):
             fn(p, *a, **k)
             e1.record()
             cin = 3 if p.Cin == 8 else p.Cin     # algorithmic: the RGB stem is 3 of the 8 padded channels
-            records.append((e0, e1, 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S, 'strip' if (is_strip(p) and k.get('bias') is None) else 'other'))
+            fam = 'strip' if (is_strip(p) and k.get('bias') is None) else 'other'
+            if k.get('bn') is not None:      # data gradient carrying a BatchNorm unit's masking + backward reduce in its epilogue (another instantiation)
+                fam += '_bn'
+            records.append((e0, e1, 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S, fam))
         return wrapper
 
     def timed_bytes(fn, family, nbytes=None):
@@ -120,7 +123,7 @@ def kernel_rooflines(model, steps, overlap):
     patched = {'conv2d_fwd': timed_conv(ops.conv2d_fwd), 'conv2d_dgrad': timed_conv(ops.conv2d_dgrad)}
     for name in ('bn_act_fwd', 'bn_pool_fwd'):
         patched[name] = timed_bytes(getattr(ops, name), 'bn_fwd')
-    for name in ('bn_act_bwd_fused', 'bn_act_bwd_reduce', 'bn_act_bwd_apply', 'bn_pool_bwd_reduce', 'bn_pool_bwd_apply'):
+    for name in ('bn_act_bwd_fused', 'bn_act_bwd_reduce', 'bn_act_bwd_apply', 'bn_pool_bwd_reduce', 'bn_pool_bwd_apply', 'stem_pool_bwd_wgrad'):
         patched[name] = timed_bytes(getattr(ops, name), 'bn_bwd')
     patched['loss_fwd_bwd'] = timed_bytes(ops.loss_fwd_bwd, 'loss')
     # p, g, m, v read + p, m, v written + the 16-bit copy = 30 B / parameter (SURVEY 8d counts 28 without the copy; the gradient zeroing adds 4 more)
@@ -141,7 +144,7 @@ def kernel_rooflines(model, steps, overlap):
             setattr(ops, n, f)
         model.overlap_wgrad, model.g.on_bucket = saved_overlap, saved_bucket
     out = {}
-    for family in ('strip', 'other', 'bn_fwd', 'bn_bwd', 'loss', 'optimizer'):
+    for family in ('strip', 'strip_bn', 'other', 'other_bn', 'bn_fwd', 'bn_bwd', 'loss', 'optimizer'):
         rs = [r for r in records if r[3] == family]
         t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rs)
         work = sum(r[2] for r in rs)
@@ -346,7 +349,8 @@ def main():
         traffic, traffic_src = strip_hbm_traffic()
         tf = alone['strip']['rate'] / 1e12
         tf_in = instep['strip']['rate'] / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel (3x3 stride-1 conv forward + data-gradient launches, all tile variants)',
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel<.., false> (3x3 stride-1 conv forward + plain data-gradient launches, all tile '
+                                                      'variants; the data gradients that also carry a BatchNorm reduce are the dgrad_bn entry)',
                            'achieved': round(tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_TFLOPS, 4),
                            'traffic': traffic, 'traffic_unit': 'bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), ' + traffic_src,
                            'avg_launch_ms': round(alone['strip']['avg_launch_ms'], 5), 'launches_per_step': alone['strip']['launches_per_step'],
@@ -354,12 +358,21 @@ def main():
                                      'two-stream schedule the headline runs, where concurrent weight-gradient kernels share the CUs',
                            'in_step': {'achieved': round(tf_in, 2), 'frac': round(tf_in / PEAK_BF16_TFLOPS, 4),
                                        'avg_launch_ms': round(instep['strip']['avg_launch_ms'], 5)},
+                           'dgrad_bn': {'kernel': 'conv3x3_strip_kernel<.., true> / igemm_fwd_kernel<.., true>: data gradient + ReLU masking + BatchNorm-'
+                                                  'backward partial sums of the unit it completes (reads y and the sign bytes on top of the conv operands)',
+                                        'strip_achieved': round(alone['strip_bn']['rate'] / 1e12, 2),
+                                        'strip_frac': round(alone['strip_bn']['rate'] / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                        'strip_in_step_achieved': round(instep['strip_bn']['rate'] / 1e12, 2),
+                                        'strip_avg_launch_ms': round(alone['strip_bn']['avg_launch_ms'], 5),
+                                        'strip_launches_per_step': alone['strip_bn']['launches_per_step'],
+                                        'igemm_achieved': round(alone['other_bn']['rate'] / 1e12, 2),
+                                        'igemm_launches_per_step': alone['other_bn']['launches_per_step']},
                            'other_conv': {'kernel': 'igemm_fwd_kernel (stem, stride-2, 1x1, fused-concat launches)',
                                           'achieved': round(alone['other']['rate'] / 1e12, 2), 'in_step_achieved': round(instep['other']['rate'] / 1e12, 2),
                                           'avg_launch_ms': round(alone['other']['avg_launch_ms'], 5),
                                           'launches_per_step': alone['other']['launches_per_step']}}
         names = {'bn_fwd': 'bn_act_fwd / bn_pool_fwd (BatchNorm apply + ReLU + residual, stem BN + max-pool)',
-                 'bn_bwd': 'bn_bwd_fused / bn_bwd_reduce + apply / pooled variants (BatchNorm backward)',
+                 'bn_bwd': 'bn_bwd_apply (+ reduce / fused where the data gradient does not carry the reduce) / stem_pool_bwd_wgrad (BatchNorm backward)',
                  'loss': 'loss_assign + loss_main + loss_finalize (YOLOv3 loss forward + d(logits))',
                  'optimizer': 'radam_l2_kernel (RAdam + L2, 30 B / parameter)'}
         out['hbm'] = {'peak': HBM_PEAK_GBS, 'achievable': HBM_ACHIEVABLE_GBS, 'unit': 'GB/s',

@@ -95,15 +95,18 @@ int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* sr
 /* dx[N,H,W,Cin] (=|+=) conv_transpose(dy[N,Ho,Wo,Cout], w).  Cin must be a multiple of 64.  accumulate != 0 adds into dx. */
 int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
                       void* stream);
+/* dx = addend + conv_transpose(dy, w): accumulate = 1 with the other contribution left where it was produced (no copy into dx first). */
+int yolo_conv2d_dgrad_add(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* stream);
 /* The same with the BatchNorm-backward REDUCE of the unit whose output gradient dx is, in the epilogue (the reference differentiates
  * Conv2D -> BatchNormalization -> ReLU chains by autodiff, basic_backbone.py:68-90; this is that chain's backward pass without the
  * separate statistics pass): dx receives the MASKED gradient g = (accumulated) dx where the unit's ReLU was positive (relu_mask: the sign
  * bytes of yolo_bn_act_fwd_mask, null for a linear unit), and partial[rows][3][Cin] (rows = yolo_conv2d_dgrad_bn_rows(p), allocated
  * ZEROED by the caller) the per-tile sums of g, g*xhat(y, mean, rstd) and, with y2, g*xhat(y2, mean2, rstd2).  yolo_bn_bwd_finalize over
  * `partial` and yolo_bn_act_bwd_apply(relu = 0) on dx finish the unit.  No grid barrier: safe next to collective kernels.
+ * addend (may be NULL): the fan-in contribution is read from this buffer instead of dx (implies accumulate), see yolo_conv2d_dgrad_add.
  * yolo_conv2d_dgrad_bn_rows < 0: this problem cannot take the fused form (N*H*W*Cin >= 2^31). */
 int yolo_conv2d_dgrad_bn_rows(const yolo_conv_problem* p);
-int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend,
                          const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2,
                          const float* mean2, const float* rstd2, float* partial, void* stream);
 /* dw[Cout][R][S][Cin] += x^T * dy (float32 atomics; the caller zeroes dw once per step).  split_k <= 0 = auto. */

@@ -243,6 +243,14 @@ def test_dgrad_with_bn_reduce_epilogue(dev, case):
         want = want * bits
     want = want.reshape(M, Cin)
     assert torch.equal(fused.reshape(M, Cin).float(), want)
+    if acc:   # the fan-in contribution read from its own buffer instead of dx: same bits, dx need not be initialised
+        for kw in (dict(), dict(bn=dict(bn, partial=torch.zeros_like(partial)))):
+            other = torch.full_like(base, float('nan'))
+            ops.conv2d_dgrad(p, dy, w_dg, other, addend=base, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(other.view(torch.int16), (fused if kw else plain).view(torch.int16))
+            if kw:
+                assert torch.equal(kw['bn']['partial'], partial)
     # reference sums from the existing reduce kernel on the plain result
     P = ops.reduce_rows(M, Cin)
     ref = torch.zeros(P, 3, Cin, device=dev)

@@ -55,6 +55,7 @@ struct BnEpi {
   const bf16_t* y;  const float* mean;  const float* rstd;
   const bf16_t* y2; const float* mean2; const float* rstd2;
   float* partial;
+  const bf16_t* addend;   // fan-in source of an accumulating data gradient when it is not the output buffer itself (any instantiation)
 };
 struct Epi { float* ssum; float* ssq; BnEpi bn; };
 
@@ -221,7 +222,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
             }
             off[k] = (unsigned)mo * (unsigned)ldy + (unsigned)c;
             yv[k] = *reinterpret_cast<const uint4*>(bn.y + off[k]);
-            if (accumulate) ev[k] = *reinterpret_cast<const uint4*>(Y + off[k]);
+            if (accumulate) ev[k] = *reinterpret_cast<const uint4*>((bn.addend ? bn.addend : Y) + off[k]);
             mk[k] = bn.mask ? (unsigned)bn.mask[off[k] >> 3] : 0xffu;
           }
         }
@@ -288,7 +289,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
         if (accumulate) {                             // gradient fan-in: y += tile (float32 add, one rounding)
           float a8[8], b8[8];
           unpack_bf8(v, a8);
-          unpack_bf8(*reinterpret_cast<const uint4*>(yp), b8);
+          unpack_bf8(*reinterpret_cast<const uint4*>(bn.addend ? bn.addend + ((size_t)mo * ldy + n0 + ch * 8) : yp), b8);
 #pragma unroll
           for (int j = 0; j < 8; ++j) a8[j] += b8[j];
           v = pack_bf8(a8);
@@ -1552,6 +1553,20 @@ extern "C" int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, con
   return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate, Epi{}, p->Cin, (hipStream_t)stream);
 }
 
+// dx = addend + conv_transpose(dy, w): the fan-in add of yolo_conv2d_dgrad(accumulate = 1) with the other contribution read from ITS buffer
+// (e.g. the masked gradient of the residual unit that feeds dx's tensor through an identity shortcut) -- that contribution is then never
+// copied into dx first
+extern "C" int yolo_conv2d_dgrad_add(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, const void* addend,
+                                     void* stream) {
+  YOLO_CHECK_ARG(dy && w_dgrad && dx && addend, "null pointer");
+  Gather g;
+  int rc = dgrad_gather(p, dy, &g);
+  if (rc) return rc;
+  Epi e = {};
+  e.bn.addend = (const bf16_t*)addend;
+  return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, 1, e, p->Cin, (hipStream_t)stream);
+}
+
 // rows of the [rows][3][Cin] partial-sum buffer yolo_conv2d_dgrad_bn fills (one per pixel tile, x 4 parity classes on the stride-2 path);
 // rows a launch does not write (classes smaller than the grid) must stay zero: allocate the buffer zeroed, nothing else writes it
 extern "C" int yolo_conv2d_dgrad_bn_rows(const yolo_conv_problem* p) {
@@ -1566,7 +1581,7 @@ extern "C" int yolo_conv2d_dgrad_bn_rows(const yolo_conv_problem* p) {
 // epilogue (see BnEpi): dx receives the masked gradient g (relu_mask: the unit's sign bytes from yolo_bn_act_fwd_mask, or null for a
 // linear unit), partial[rows][3][Cin] the tile sums of g, g xhat(y, mean, rstd) and -- if y2 is given -- g xhat(y2, mean2, rstd2).
 // yolo_bn_bwd_finalize over `partial` and yolo_bn_act_bwd_apply with relu = 0 on dx complete the unit's backward pass.
-extern "C" int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+extern "C" int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend,
                                     const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2,
                                     const float* mean2, const float* rstd2, float* partial, void* stream) {
   YOLO_CHECK_ARG(dy && w_dgrad && dx, "null pointer");
@@ -1581,7 +1596,8 @@ extern "C" int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, 
   e.bn.y = (const bf16_t*)y; e.bn.mean = mean; e.bn.rstd = rstd;
   e.bn.y2 = (const bf16_t*)y2; e.bn.mean2 = mean2; e.bn.rstd2 = rstd2;
   e.bn.partial = partial;
-  return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate, e, p->Cin, (hipStream_t)stream);
+  e.bn.addend = (const bf16_t*)addend;             // non-null: the fan-in source instead of dx itself (implies accumulate)
+  return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, (accumulate || addend) ? 1 : 0, e, p->Cin, (hipStream_t)stream);
 }
 
 namespace {

@@ -444,6 +444,9 @@ class Graph(object):
             for op in self.tape:
                 if isinstance(op, ApplyOp):
                     op.plan_fusion()
+            for op in self.tape:
+                if isinstance(op, ApplyOp):
+                    op.plan_shortcut_alias()
         # gradient buckets for data-parallel overlap, by backbone stage (parameters are laid out in creation order, backward runs in reverse):
         #   [first stride-32 conv, n)   module512 + the three heads, ~70 % of the parameters: complete ~40 % into the backward pass
         #   [first stride-8 conv, that) the stride-8 / stride-16 stages
@@ -658,6 +661,7 @@ class ConvOp(object):
         y = self.y
         self.acc = []
         self.bn_epi = None          # set by ApplyOp.plan_fusion: this data gradient completes a BatchNorm unit's output gradient
+        self.addend = None          # set by ApplyOp.plan_shortcut_alias: the fan-in contribution is read from that Val's .grad
         if not self.needs_dgrad():
             return
         x = y.x
@@ -699,7 +703,8 @@ class ConvOp(object):
             N, H, W, _ = x.shape
             ops.upcat_split_bwd(self.dcat, a.grad, self.acc[0], b.grad, self.acc[1], N, H, W, a.shape[3], b.shape[3])
         else:
-            ops.conv2d_dgrad(y.p, y.dy, self.w_dg, x.grad, accumulate=self.acc[0], bn=self.bn_epi)
+            ops.conv2d_dgrad(y.p, y.dy, self.w_dg, x.grad, accumulate=self.acc[0], bn=self.bn_epi,
+                             addend=None if self.addend is None else self.addend.grad)
 
 
 class MixConvOp(object):
@@ -810,6 +815,20 @@ class ApplyOp(object):
             o.grad_init = True
             o.grad_writers.append(self)
         self.producer = None
+        self.skip_dres = False
+
+    def plan_shortcut_alias(self):
+        """identity shortcut of a residual unit whose masked gradient g already sits in out.grad (left there by the producer's epilogue):
+        the shortcut's gradient IS g.  If the shortcut tensor's gradient has exactly one more contribution, a data-gradient convolution
+        that runs after this unit and accumulates, that launch reads g from out.grad directly and the copy into the shortcut's
+        gradient buffer (2 B / element written, then read back) is dropped"""
+        o = self.o_src
+        if self.producer is None or o is None or self.o_bn is not None or o.kind != 'act' or self.o_acc:
+            return
+        w = o.grad_writers
+        if len(w) == 2 and w[0] is self and isinstance(w[1], ConvOp) and w[1].y.x is o:
+            w[1].addend = self.out
+            self.skip_dres = True
 
     def _reduce_operands(self):
         """(y1, bn1, y2, bn2) of the backward reduction: quantity 1 belongs to the main BN if there is one, else to the shortcut BN"""
@@ -881,7 +900,7 @@ class ApplyOp(object):
         if o is not None:
             if ob is not None:
                 kw.update(y2=o.buf, a2=ob.scale, mean2=ob.mean, rstd2=ob.rstd, k1b=ob.k1, k2b=ob.k2, dy2=o.dy)
-            else:
+            elif not self.skip_dres:
                 kw.update(dres=o.grad, acc_dres=self.o_acc)
         ops.bn_act_bwd_apply(out.grad, sign, relu, self.M, self.C, **kw)
 

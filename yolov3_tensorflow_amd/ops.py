@@ -57,13 +57,17 @@ def conv2d_fwd(p, src1, w_fwd, y, src0=None, bias=None, stat_sum=None, stat_sq=N
                                       1 if y.dtype == torch.float32 else 0, _p(stat_sum), _p(stat_sq), _stream()), 'yolo_conv2d_fwd')
 
 
-def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False, bn=None):
+def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False, bn=None, addend=None):
     """``bn`` = dict(mask, y, mean, rstd, partial[, y2, mean2, rstd2]): dx is the output gradient of a BatchNorm unit -- leave the masked
-    gradient in dx and the unit's backward partial sums in ``partial`` (yolo_conv2d_dgrad_bn)"""
+    gradient in dx and the unit's backward partial sums in ``partial`` (yolo_conv2d_dgrad_bn).  ``addend``: dx = addend + gradient
+    (the fan-in add with the other contribution read from its own buffer)"""
     if bn is None:
-        check(_lib.load().yolo_conv2d_dgrad(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _stream()), 'yolo_conv2d_dgrad')
+        if addend is not None:
+            check(_lib.load().yolo_conv2d_dgrad_add(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), _p(addend), _stream()), 'yolo_conv2d_dgrad_add')
+        else:
+            check(_lib.load().yolo_conv2d_dgrad(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _stream()), 'yolo_conv2d_dgrad')
         return
-    check(_lib.load().yolo_conv2d_dgrad_bn(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _p(bn.get('mask')), _p(bn['y']),
+    check(_lib.load().yolo_conv2d_dgrad_bn(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _p(addend), _p(bn.get('mask')), _p(bn['y']),
                                            _p(bn['mean']), _p(bn['rstd']), _p(bn.get('y2')), _p(bn.get('mean2')), _p(bn.get('rstd2')),
                                            _p(bn['partial']), _stream()), 'yolo_conv2d_dgrad_bn')
 
