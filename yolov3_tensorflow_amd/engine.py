@@ -445,7 +445,7 @@ class Graph(object):
                 if isinstance(op, ApplyOp):
                     op.plan_fusion()
             for op in self.tape:
-                if isinstance(op, ApplyOp):
+                if isinstance(op, ApplyOp) and os.environ.get('YOLO_SHORTCUT_ALIAS', '1') != '0':
                     op.plan_shortcut_alias()
         # gradient buckets for data-parallel overlap, by backbone stage (parameters are laid out in creation order, backward runs in reverse):
         #   [first stride-32 conv, n)   module512 + the three heads, ~70 % of the parameters: complete ~40 % into the backward pass
