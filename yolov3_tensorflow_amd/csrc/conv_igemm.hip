@@ -174,6 +174,33 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
     // NHWC rows -- straight from the accumulators each instruction wrote 16 scattered 32-byte segments, which cost more than the
     // MFMAs of the whole tile on the 64-channel layers (ablation: 39 of 70 us)
     constexpr int OLD = BN * 2 + 16;                  // LDS row stride in bytes (16-byte pad: conflict-free 8-byte writes)
+    // fused BatchNorm reduce: geometry of the write loop (a thread keeps its channel chunk and walks rows) and the global reads of its
+    // first NB rows (y, the fan-in addend, the sign byte), requested NOW so that they fly under the staging of the tile
+    constexpr int E_CPR = BN / 8, E_RG = NW * 64 / E_CPR, E_ITER = BM / E_RG, E_NB = E_ITER < 4 ? E_ITER : 4;
+    const int e_ch = tid % E_CPR, e_rg = tid / E_CPR, e_c = n0 + e_ch * 8;
+    uint4 e_yv[E_NB], e_ev[E_NB];
+    unsigned e_mk[E_NB], e_off[E_NB];
+    auto e_load = [&](int it0) {
+#pragma unroll
+      for (int k = 0; k < E_NB; ++k) {
+        const int row = e_rg + (it0 + k) * E_RG, m = m0 + row;
+        e_off[k] = 0xffffffffu;                        // element offsets (the host refuses tensors of 2^31 elements or more)
+        if (m < M) {
+          int mo = m;
+          if (cv.on) {
+            int n_, rem, hh, ww;
+            fast_divmod(m, cv.Hc * cv.Wc, cv.rhw, n_, rem);
+            fast_divmod(rem, cv.Wc, cv.rw, hh, ww);
+            mo = (n_ * cv.OH + 2 * hh + cv.ph) * cv.OW + 2 * ww + cv.pw;
+          }
+          e_off[k] = (unsigned)mo * (unsigned)ldy + (unsigned)e_c;
+          e_yv[k] = *reinterpret_cast<const uint4*>(bn.y + e_off[k]);
+          if (accumulate) e_ev[k] = *reinterpret_cast<const uint4*>((bn.addend ? bn.addend : reinterpret_cast<const bf16_t*>(Yv)) + e_off[k]);
+          e_mk[k] = bn.mask ? (unsigned)bn.mask[e_off[k] >> 3] : 0xffu;
+        }
+      }
+    };
+    if constexpr (BNEPI) e_load(0);
     __syncthreads();                                  // every wave is done with the operand ring
 #pragma unroll
     for (int b = 0; b < PT; ++b) {
@@ -197,44 +224,24 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
     constexpr int CPR = BN / 8;                       // 16-byte chunks per row
     bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
     if constexpr (BNEPI) {   // data gradient of a BatchNorm unit's output: mask, store g, partial sums of g and g xhat
-      constexpr int RG = NW * 64 / CPR;               // a thread keeps its channel chunk (NW * 64 is a multiple of CPR) and walks rows
-      constexpr int ITER = BM / RG, NB = ITER < 4 ? ITER : 4;
+      constexpr int RG = E_RG, ITER = E_ITER, NB = E_NB;
       static_assert(BM % RG == 0 && ITER % NB == 0 && RG * BN * 4 <= BM * (BN * 2 + 16), "epilogue geometry");
-      const int ch = tid % CPR, rg = tid / CPR, c = n0 + ch * 8;
+      const int ch = e_ch, rg = e_rg, c = e_c;
       float mu[8], rs[8], s0[8], s1[8], s2[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { mu[j] = bn.mean[c + j]; rs[j] = bn.rstd[c + j]; s0[j] = s1[j] = s2[j] = 0.f; }
 #pragma unroll
       for (int it0 = 0; it0 < ITER; it0 += NB) {
-        uint4 yv[NB], ev[NB];
-        unsigned mk[NB], off[NB];                     // element offsets (the host refuses tensors of 2^31 elements or more)
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {                // the batch's global reads in flight together
-          const int row = rg + (it0 + k) * RG, m = m0 + row;
-          off[k] = 0xffffffffu;
-          if (m < M) {
-            int mo = m;
-            if (cv.on) {
-              int n_, rem, hh, ww;
-              fast_divmod(m, cv.Hc * cv.Wc, cv.rhw, n_, rem);
-              fast_divmod(rem, cv.Wc, cv.rw, hh, ww);
-              mo = (n_ * cv.OH + 2 * hh + cv.ph) * cv.OW + 2 * ww + cv.pw;
-            }
-            off[k] = (unsigned)mo * (unsigned)ldy + (unsigned)c;
-            yv[k] = *reinterpret_cast<const uint4*>(bn.y + off[k]);
-            if (accumulate) ev[k] = *reinterpret_cast<const uint4*>((bn.addend ? bn.addend : Y) + off[k]);
-            mk[k] = bn.mask ? (unsigned)bn.mask[off[k] >> 3] : 0xffu;
-          }
-        }
+        if (it0 > 0) e_load(it0);                     // (256 x 128 tiles only: the second batch of rows)
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-          if (off[k] != 0xffffffffu) {
+          if (e_off[k] != 0xffffffffu) {
             const int row = rg + (it0 + k) * RG;
             uint4 v = *reinterpret_cast<const uint4*>(smem + row * OLD + ch * 16);
             float g8[8], y8[8];
             if (accumulate) {                         // gradient fan-in: float32 add, one rounding (as the plain path below)
               unpack_bf8(v, g8);
-              unpack_bf8(ev[k], y8);
+              unpack_bf8(e_ev[k], y8);
 #pragma unroll
               for (int j = 0; j < 8; ++j) g8[j] += y8[j];
               v = pack_bf8(g8);
@@ -242,15 +249,15 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
             unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              w4[q] = (((mk[k] >> (2 * q)) & 1u) ? (w4[q] & 0xffffu) : 0u) | (((mk[k] >> (2 * q + 1)) & 1u) ? (w4[q] & 0xffff0000u) : 0u);
+              w4[q] = (((e_mk[k] >> (2 * q)) & 1u) ? (w4[q] & 0xffffu) : 0u) | (((e_mk[k] >> (2 * q + 1)) & 1u) ? (w4[q] & 0xffff0000u) : 0u);
             v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-            *reinterpret_cast<uint4*>(Y + off[k]) = v;
+            *reinterpret_cast<uint4*>(Y + e_off[k]) = v;
             unpack_bf8(v, g8);
-            unpack_bf8(yv[k], y8);
+            unpack_bf8(e_yv[k], y8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s0[j] += g8[j]; s1[j] += g8[j] * ((y8[j] - mu[j]) * rs[j]); }
             if (bn.y2) {                              // shortcut BatchNorm of a down-sampling block (3 units per step): loaded in place
-              unpack_bf8(*reinterpret_cast<const uint4*>(bn.y2 + off[k]), y8);
+              unpack_bf8(*reinterpret_cast<const uint4*>(bn.y2 + e_off[k]), y8);
 #pragma unroll
               for (int j = 0; j < 8; ++j) s2[j] += g8[j] * ((y8[j] - bn.mean2[c + j]) * bn.rstd2[c + j]);
             }
