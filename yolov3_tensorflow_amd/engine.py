@@ -816,6 +816,7 @@ class ApplyOp(object):
             o.grad_writers.append(self)
         self.producer = None
         self.skip_dres = False
+        self.skip_dy = False
 
     def plan_shortcut_alias(self):
         """identity shortcut of a residual unit whose masked gradient g already sits in out.grad (left there by the producer's epilogue):
@@ -823,7 +824,15 @@ class ApplyOp(object):
         that runs after this unit and accumulates, that launch reads g from out.grad directly and the copy into the shortcut's
         gradient buffer (2 B / element written, then read back) is dropped"""
         o = self.o_src
-        if self.producer is None or o is None or self.o_bn is not None or o.kind != 'act' or self.o_acc:
+        # out.grad IS the gradient g of this unit's inputs: left masked by the producer's epilogue, or -- a plain sum without BatchNorm
+        # and ReLU (ResNet18-v2's residual adds, resnet18_v2.py:38-58) -- as it arrived
+        plain_sum = self.m_bn is None and self.o_bn is None and not self.relu
+        if self.producer is None and not plain_sum:
+            return
+        if plain_sum and self.m_src.kind == 'conv' and self.m_dst == 'dy':
+            self.m_src.dy = self.out.grad          # the convolution's output gradient is this buffer: no copy (its kernels read y.dy when launched)
+            self.skip_dy = True
+        if o is None or self.o_bn is not None or o.kind != 'act' or self.o_acc:
             return
         w = o.grad_writers
         if len(w) == 2 and w[0] is self and isinstance(w[1], ConvOp) and w[1].y.x is o:
@@ -893,10 +902,13 @@ class ApplyOp(object):
             if b2 is not None:
                 b2.bwd_finalize(self.pflat, self.P, self.C, 2, self.M)
         kw = {}
+        if self.skip_dy and (o is None or self.skip_dres):
+            return                                  # a plain sum whose operands read out.grad in place: nothing to launch
         m_dst = m.dy if self.m_dst == 'dy' else m.grad
         if mb is not None:
             kw.update(y=m.buf, a1=mb.scale, mean=mb.mean, rstd=mb.rstd, k1=mb.k1, k2=mb.k2)       # gamma * rstd == forward scale
-        kw.update(dy=m_dst, acc_dy=self.m_acc)
+        if not self.skip_dy:
+            kw.update(dy=m_dst, acc_dy=self.m_acc)
         if o is not None:
             if ob is not None:
                 kw.update(y2=o.buf, a2=ob.scale, mean2=ob.mean, rstd2=ob.rstd, k1b=ob.k1, k2b=ob.k2, dy2=o.dy)
