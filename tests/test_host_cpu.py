@@ -119,6 +119,27 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
     assert c['bn_finalize'] + 4 * c['bn_finalize_grouped'] == n_bn      # MixNet: one grouped launch per 4 group BatchNorms
     if n_dw:
         assert c['dwconv_mix_fwd'] == 8 and c['dwconv_mix_dgrad'] == 8 and c['dwconv_mix_wgrad'] == 8
+    # backward plan of the BatchNorm units: the data gradient that writes a unit's output gradient LAST carries its reduce (every unit whose
+    # last writer is a plain convolution: all but the two fed by the upsample + concat split, MixNet's depthwise-fed ones, v2's plain sums);
+    # such a unit then launches finalize + apply only; identity shortcuts read the masked gradient in place
+    from yolov3_tensorflow_amd import engine
+    units = [op for op in m.g.tape if isinstance(op, engine.ApplyOp)]
+    fused = [op for op in units if op.producer is not None]
+    assert len(units) == {'resnet-18': 23, 'resnet-18-v2': 34, 'mixnet-18': 23}[backbone]
+    assert len(fused) == {'resnet-18': 21, 'resnet-18-v2': 22, 'mixnet-18': 13}[backbone]
+    for op in units:
+        w = op.out.grad_writers
+        last_is_conv = bool(w) and isinstance(w[-1], engine.ConvOp) and w[-1].y.x is op.out
+        assert (op.producer is not None) == (last_is_conv and (op.m_bn is not None or op.o_bn is not None))
+        if op.producer is not None:
+            assert op.producer.bn_epi['partial'] is op.fpartial and op.fpartial.shape[1:] == (3, op.C) and float(op.fpartial.abs().sum()) == 0.0
+    # (the mocked single-launch kernel 'declines', so every unit without a producer also takes the three-kernel path here)
+    assert c['bn_act_bwd_reduce'] == len([op for op in units if op.producer is None and (op.m_bn is not None or op.o_bn is not None)])
+    n_alias = sum(1 for op in units if op.skip_dres)
+    assert backbone != 'resnet-18' or n_alias == 4, n_alias          # the second block of each stage has the identity shortcut
+    for op in m.g.tape:
+        if isinstance(op, engine.ConvOp) and op.addend is not None:
+            assert op.acc == [True] and any(u.skip_dres and u.out is op.addend for u in units)
 
 
 def test_weight_layout_roundtrip_and_checkpoint(mocked_kernels, tmp_path):
