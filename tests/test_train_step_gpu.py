@@ -198,6 +198,51 @@ def test_forward_loss_grads_and_step(backbone, rect, compute_dtype, focal):
     torch.testing.assert_close(torch.as_tensor(w1[bn0 + '/moving_mean']), oi.det.params.p[bn0 + '/moving_mean'].detach(), rtol=2e-2, atol=1e-3)
 
 
+@pytest.mark.parametrize('backbone', ['resnet-18', 'resnet-18-v2', 'mixnet-18'])
+def test_backward_plans_agree(backbone, monkeypatch):
+    """the backward pass as planned by default (BatchNorm reduce on the data gradient, stem backward in one kernel, shortcut gradients read in
+    place, ReLU sign bytes) against the round-1 plan (separate BatchNorm-backward kernels reading the activation, pool apply + stem weight
+    gradient, copies) on the same weights and batch: the two are the same arithmetic up to float32 summation order and the folded BatchNorm
+    constants of the stem kernel, so the first step's gradients agree to 16-bit rounding noise and three steps end at the same loss"""
+    H = W = 128
+    images, labels = make_batch(4, H, W, 6, 7, seed=3)
+    res = []
+    for plan in ('default', 'round1'):
+        for k in ('YOLO_DGRAD_BN', 'YOLO_STEM_BWD', 'YOLO_SHORTCUT_ALIAS', 'YOLO_RELU_MASK'):
+            if plan == 'round1':
+                monkeypatch.setenv(k, '0')
+            else:
+                monkeypatch.delenv(k, raising=False)
+        model, loss, opt, grids = build(backbone, H, W, 4, 7, rect=-1)
+        from yolov3_tensorflow_amd import engine
+        units = [op for op in model.g.tape if isinstance(op, engine.ApplyOp)]
+        assert (sum(op.producer is not None for op in units) > 0) == (plan == 'default')
+        assert any(isinstance(op, engine.PoolOp) and (op.conv_op is not None) == (plan == 'default') for op in model.g.tape)
+        model.use_hip_graph = False
+        model.stage_batch(torch.from_numpy(images), torch.from_numpy(labels))
+        model.g.training = True
+        model._fwd_bwd()
+        torch.cuda.synchronize()
+        grad = model.g.ps.grad.detach().float().cpu().numpy().copy()
+        model.g.ps.grad.zero_()
+        if model.loss_obj.current_num is not None:
+            model.loss_obj.current_num.zero_()
+        losses = []
+        for _ in range(3):
+            model.run_step()
+            losses.append(float(model.loss_value.item()))
+        res.append((grad, losses))
+        del model, loss, opt
+    (g_new, l_new), (g_old, l_old) = res
+    print(backbone, 'gradient rel l2 between the plans %.2e' % rel_l2(g_new, g_old), l_new, l_old)
+    assert rel_l2(g_new, g_old) < 2e-2, rel_l2(g_new, g_old)          # bf16 activations: each plan is ~1e-2 from the float32 gradient
+    assert abs(l_new[0] - l_old[0]) <= 1e-6 * abs(l_old[0])           # the forward pass is the same code
+    # RAdam's first (un-rectified, lr 1e-3) steps move every weight by ~lr whatever the gradient's size: rounding-level differences of
+    # the gradient change a step by a visible amount -- the same spread the bf16 run shows against the float32 oracle
+    assert abs(l_new[1] - l_old[1]) <= 3e-3 * abs(l_old[1]), (l_new, l_old)
+    assert abs(l_new[2] - l_old[2]) <= 2e-2 * abs(l_old[2]), (l_new, l_old)
+
+
 def test_loss_curve_graph_replay():
     """6 training steps with hipGraph replay vs the float32 oracle, at the learning rate the reference's scheduler applies in
     its first epochs (1e-5, configs.py:16-17).  Steps 1-5 take RAdam's momentum branch, step 6 the adaptive one (rho_t >= 5).
