@@ -36,6 +36,11 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[K][8], int C, fl
 
 __device__ __forceinline__ uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void st16(bf16_t* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+// eight consecutive floats of a per-channel vector (c is a multiple of 8: 32-byte aligned)
+__device__ __forceinline__ void ld8f(const float* __restrict__ p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
 
 // ---- plain per-channel sum / sum of squares of a bf16 [M][C] tensor -> partial[grid][2][C] ----
 __global__ __launch_bounds__(EW_THREADS) void bn_stats_kernel(const bf16_t* __restrict__ x, int M, int C, float* __restrict__ partial) {
@@ -211,20 +216,27 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __
                                                                 bf16_t* __restrict__ out, size_t nchunks, int C, int relu,
                                                                 uint8_t* __restrict__ mask) {
   const int CV = C >> 3;
+  // the grid stride is a multiple of CV (CV divides the 256 threads of a workgroup): a thread keeps its channel chunk, so the per-channel
+  // constants are loaded ONCE -- in the loop they were 16-32 four-byte loads per 16-byte chunk, and the address units, not HBM, set the pace
+  const int c = (int)(((size_t)blockIdx.x * EW_THREADS + threadIdx.x) % CV) * 8;
+  float sc[8], sh[8], sc2[8], sh2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = sc2[j] = 1.f; sh[j] = sh2[j] = 0.f; }
+  if (scale) { ld8f(scale + c, sc); ld8f(shift + c, sh); }             // (uniform branches, two 16-byte loads per array, one wait)
+  if (scale2) { ld8f(scale2 + c, sc2); ld8f(shift2 + c, sh2); }
   for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_THREADS) {
-    const int c = (int)(i % CV) * 8;
     float v[8];
     unpack_bf8(ld16(y + i * 8), v);
     if (scale) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = v[j] * scale[c + j] + shift[c + j];
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
     }
     if (res) {
       float r[8];
       unpack_bf8(ld16(res + i * 8), r);
       if (scale2) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = r[j] * scale2[c + j] + shift2[c + j];
+        for (int j = 0; j < 8; ++j) r[j] = r[j] * sc2[j] + sh2[j];
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += r[j];
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 
 // dy = a * (g - k1 - xhat * k2), a = gamma * rstd  (a == nullptr: dy = g, no BN);  optional second BN branch (y2 ...);
 // optional dres (=|+=) g.
-template <typename G>
+template <typename G, bool HAS2>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf16_t* __restrict__ y, const float* __restrict__ a1,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   const float* __restrict__ k1, const float* __restrict__ k2,
@@ -488,17 +500,24 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf
                                                                   size_t M, int C) {
   const int CV = C >> 3;
   const size_t total = M * CV;
+  // a thread keeps its channel chunk (the grid stride is a multiple of CV): the per-channel constants live in registers, not in 40-80
+  // four-byte loads per chunk
+  const int cv = (int)(((size_t)blockIdx.x * EW_THREADS + threadIdx.x) % CV);
+  const int c = cv * 8;
+  float ca[8], ck1[8], cmu[8], crs[8], ck2[8], da[8], dk1[8], dmu[8], drs[8], dk2[8];      // (the second set only in the HAS2 instantiation)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ca[j] = ck1[j] = cmu[j] = crs[j] = ck2[j] = da[j] = dk1[j] = dmu[j] = drs[j] = dk2[j] = 0.f;
+  if (a1) { ld8f(a1 + c, ca); ld8f(k1 + c, ck1); ld8f(mean + c, cmu); ld8f(rstd + c, crs); ld8f(k2 + c, ck2); }   // uniform branch, 16-byte loads
+  if (HAS2) { ld8f(a2 + c, da); ld8f(k1b + c, dk1); ld8f(mean2 + c, dmu); ld8f(rstd2 + c, drs); ld8f(k2b + c, dk2); }
   for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_THREADS) {
-    const int cv = (int)(i % CV);
     const size_t row = i / CV;
-    const int c = cv * 8;
     float g[8], v[8], o[8];
     gp.load(row, cv, g);
     if (dy) {
       if (a1) {
         unpack_bf8(ld16(y + i * 8), v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = a1[c + j] * (g[j] - k1[c + j] - (v[j] - mean[c + j]) * rstd[c + j] * k2[c + j]);
+        for (int j = 0; j < 8; ++j) o[j] = ca[j] * (g[j] - ck1[j] - (v[j] - cmu[j]) * crs[j] * ck2[j]);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = g[j];
@@ -510,10 +529,10 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf
       }
       st16(dy + i * 8, pack_bf8(o));
     }
-    if (dy2) {
+    if (HAS2) {
       unpack_bf8(ld16(y2 + i * 8), v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = a2[c + j] * (g[j] - k1b[c + j] - (v[j] - mean2[c + j]) * rstd2[c + j] * k2b[c + j]);
+      for (int j = 0; j < 8; ++j) o[j] = da[j] * (g[j] - dk1[j] - (v[j] - dmu[j]) * drs[j] * dk2[j]);
       st16(dy2 + i * 8, pack_bf8(o));
     }
     if (dres) {
@@ -1201,9 +1220,14 @@ extern "C" int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu
   YOLO_CHECK_ARG(!dy2 || (y2 && a2 && mean2 && rstd2 && k1b && k2b), "second BN branch incomplete");
   PlainGrad gp{(const bf16_t*)dout, (const bf16_t*)out, relu, C};
   const size_t n = (size_t)M * (C / 8);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<PlainGrad>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, gp, (const bf16_t*)y, a1,
-                     mean, rstd, k1, k2, (bf16_t*)dy, acc_dy, (const bf16_t*)y2, a2, mean2, rstd2, k1b, k2b, (bf16_t*)dy2, (bf16_t*)dres,
-                     acc_dres, (size_t)M, C);
+  if (dy2)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<PlainGrad, true>), dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, gp, (const bf16_t*)y, a1,
+                       mean, rstd, k1, k2, (bf16_t*)dy, acc_dy, (const bf16_t*)y2, a2, mean2, rstd2, k1b, k2b, (bf16_t*)dy2, (bf16_t*)dres,
+                       acc_dres, (size_t)M, C);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<PlainGrad, false>), dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, gp, (const bf16_t*)y, a1,
+                       mean, rstd, k1, k2, (bf16_t*)dy, acc_dy, (const bf16_t*)y2, a2, mean2, rstd2, k1b, k2b, (bf16_t*)dy2, (bf16_t*)dres,
+                       acc_dres, (size_t)M, C);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
@@ -1359,7 +1383,7 @@ extern "C" int yolo_bn_pool_bwd_apply(const void* dout, const void* out, const u
     return YOLO_OK;
   }
   const size_t M = (size_t)N * H * W;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<PoolGrad>, dim3(ew_grid(M * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream, gp,
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<PoolGrad, false>), dim3(ew_grid(M * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream, gp,
                      (const bf16_t*)y, a1, mean, rstd, k1, k2, (bf16_t*)dy, 0, (const bf16_t*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr,
                      (bf16_t*)nullptr, 0, M, C);
