@@ -226,14 +226,17 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __
   if (scale2) { ld8f(scale2 + c, sc2); ld8f(shift2 + c, sh2); }
   for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_THREADS) {
     float v[8];
-    unpack_bf8(ld16(y + i * 8), v);
+    const uint4 yv = ld16(y + i * 8);
+    uint4 rv = make_uint4(0u, 0u, 0u, 0u);
+    if (res) rv = ld16(res + i * 8);                  // both reads in flight before the first use
+    unpack_bf8(yv, v);
     if (scale) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
     }
     if (res) {
       float r[8];
-      unpack_bf8(ld16(res + i * 8), r);
+      unpack_bf8(rv, r);
       if (scale2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = r[j] * sc2[j] + sh2[j];
@@ -511,11 +514,17 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf
   if (HAS2) { ld8f(a2 + c, da); ld8f(k1b + c, dk1); ld8f(mean2 + c, dmu); ld8f(rstd2 + c, drs); ld8f(k2b + c, dk2); }
   for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_THREADS) {
     const size_t row = i / CV;
+    // every read of the chunk is requested before the first use (one load in flight per thread left the kernel latency-bound)
+    uint4 yv = make_uint4(0u, 0u, 0u, 0u), ov = yv, y2v = yv, rv = yv;
+    if (dy && a1) yv = ld16(y + i * 8);
+    if (dy && acc_dy) ov = ld16(dy + i * 8);
+    if (HAS2) y2v = ld16(y2 + i * 8);
+    if (dres && acc_dres) rv = ld16(dres + i * 8);
     float g[8], v[8], o[8];
     gp.load(row, cv, g);
     if (dy) {
       if (a1) {
-        unpack_bf8(ld16(y + i * 8), v);
+        unpack_bf8(yv, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = ca[j] * (g[j] - ck1[j] - (v[j] - cmu[j]) * crs[j] * ck2[j]);
       } else {
@@ -523,21 +532,21 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf
         for (int j = 0; j < 8; ++j) o[j] = g[j];
       }
       if (acc_dy) {
-        unpack_bf8(ld16(dy + i * 8), v);
+        unpack_bf8(ov, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] += v[j];
       }
       st16(dy + i * 8, pack_bf8(o));
     }
     if (HAS2) {
-      unpack_bf8(ld16(y2 + i * 8), v);
+      unpack_bf8(y2v, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = da[j] * (g[j] - dk1[j] - (v[j] - dmu[j]) * drs[j] * dk2[j]);
       st16(dy2 + i * 8, pack_bf8(o));
     }
     if (dres) {
       if (acc_dres) {
-        unpack_bf8(ld16(dres + i * 8), v);
+        unpack_bf8(rv, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] += v[j];
       }
