@@ -265,17 +265,22 @@ __global__ __launch_bounds__(EW_THREADS) void bn_pool_fwd_kernel(const bf16_t* _
                                                                  int Wo, int pt, int pl, int relu) {
   const int CV = C >> 3;
   const size_t total = (size_t)N * Ho * Wo * CV;
+  // (a thread keeps its channel chunk: the grid stride is a multiple of CV)
+  const int cv = (int)(((size_t)blockIdx.x * EW_THREADS + threadIdx.x) % CV);
+  const int c = cv * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+  if (scale) { ld8f(scale + c, sc); ld8f(shift + c, sh); }
   for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_THREADS) {
-    const int cv = (int)(i % CV);
     size_t pix = i / CV;
     const int wo = (int)(pix % Wo); pix /= Wo;
     const int ho = (int)(pix % Ho);
     const int n = (int)(pix / Ho);
-    const int c = cv * 8;
-    float sc[8], sh[8], best[8];
+    float best[8];
     int arg[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = scale ? scale[c + j] : 1.f; sh[j] = shift ? shift[c + j] : 0.f; best[j] = -INFINITY; arg[j] = 0; }
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; arg[j] = 0; }
 #pragma unroll
     for (int dh = 0; dh < 3; ++dh) {
       const int h = ho * 2 - pt + dh;
@@ -373,10 +378,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(G gp, const b
   float acc[3][8] = {};
   float mu[8], rs[8], mu2[8], rs2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    mu[j] = mean[cv * 8 + j]; rs[j] = rstd[cv * 8 + j];
-    mu2[j] = y2 ? mean2[cv * 8 + j] : 0.f; rs2[j] = y2 ? rstd2[cv * 8 + j] : 0.f;
-  }
+  for (int j = 0; j < 8; ++j) mu2[j] = rs2[j] = 0.f;
+  ld8f(mean + cv * 8, mu); ld8f(rstd + cv * 8, rs);
+  if (y2) { ld8f(mean2 + cv * 8, mu2); ld8f(rstd2 + cv * 8, rs2); }
   for (int r = blockIdx.x * RL + rl; r < M; r += gridDim.x * RL) {
     float g[8], v[8];
     gp.load((size_t)r, cv, g);
