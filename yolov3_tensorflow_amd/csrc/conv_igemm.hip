@@ -1236,9 +1236,14 @@ __global__ void repack_dgrad_kernel(const bf16_t* __restrict__ wf, bf16_t* __res
 // bf16 buffers); tile order inside a layer: tap-major, then co tile, then ci tile
 __global__ void repack_dgrad_batched_kernel(const bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, const int* __restrict__ table, int nlayers) {
   __shared__ bf16_t tile[32][33];
-  int l = 0;
-  while (l + 1 < nlayers && (int)blockIdx.x >= table[(l + 1) * 8 + 5]) ++l;
-  const int* t = table + l * 8;
+  // the layer of this tile: last l with tile_begin[l] <= blockIdx.x.  Binary search: the linear scan was up to 30 DEPENDENT scalar loads per
+  // workgroup, several microseconds for 16 K workgroups that move 2 KB each
+  int lo = 0, hi = nlayers - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= table[mid * 8 + 5]) lo = mid; else hi = mid - 1;
+  }
+  const int* t = table + lo * 8;
   const int Cout = t[2], RS = t[3], Cin = t[4], tci = t[6], tco = t[7];
   int id = blockIdx.x - t[5];
   const int tap = id / (tci * tco);
