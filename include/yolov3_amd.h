@@ -361,7 +361,9 @@ int yolo_radam_l2_step(float* params, float* grads, float* m, float* v, float* v
                        int64_t n, const float* sched, float beta1, float beta2, float eps, float grad_scale, int zero_grad,
                        float* l2_partial, int* nonfinite, void* stream);
 int yolo_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
-int yolo_sum_partials(const float* partial, int n, const float* add, float* out, void* stream);
+/* out[0] = sum of partial[0..n) (+ add[0] if add != NULL); out_plain[0] (may be NULL) = the sum without `add`: the reported loss (YOLOv3 loss +
+ * L2 terms) and the L2 terms alone from one launch */
+int yolo_sum_partials(const float* partial, int n, const float* add, float* out, float* out_plain, void* stream);
 
 #ifdef __cplusplus
 }

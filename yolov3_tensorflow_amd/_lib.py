@@ -113,7 +113,7 @@ SIGNATURES = {
     'yolo_radam_l2_blocks': (I, [I64]),
     'yolo_radam_l2_step': (I, [P, P, P, P, P, P, P, I64, P, F, F, F, F, I, P, P, P]),
     'yolo_cast_f32_to_bf16': (I, [P, P, I64, P]),
-    'yolo_sum_partials': (I, [P, I, P, P, P]),
+    'yolo_sum_partials': (I, [P, I, P, P, P, P]),
 }
 
 _libs = {}

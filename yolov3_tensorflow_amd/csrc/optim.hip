@@ -121,16 +121,20 @@ __global__ __launch_bounds__(OPT_THREADS) void cast_bf16_kernel(const float* __r
   }
 }
 
-// out[0] = sum(partial[0..n)) (+ add[0] if add)
+// out[0] = sum(partial[0..n)) (+ add[0] if add); out_plain[0] = the sum alone (if given)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, const float* __restrict__ add,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, float* __restrict__ out_plain) {
   __shared__ float red[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3] + (add ? add[0] : 0.f);
+  if (threadIdx.x == 0) {
+    const float t = red[0] + red[1] + red[2] + red[3];
+    if (out_plain) out_plain[0] = t;
+    out[0] = t + (add ? add[0] : 0.f);
+  }
 }
 
 inline int opt_grid(size_t n4) {
@@ -180,9 +184,9 @@ extern "C" int yolo_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* s
   return YOLO_OK;
 }
 
-extern "C" int yolo_sum_partials(const float* partial, int n, const float* add, float* out, void* stream) {
+extern "C" int yolo_sum_partials(const float* partial, int n, const float* add, float* out, float* out_plain, void* stream) {
   YOLO_CHECK_ARG(partial && out && n > 0, "bad argument");
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, add, out);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, add, out, out_plain);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

@@ -412,8 +412,8 @@ def cast_f32_to_bf16(x, y, n):
     check(_lib.load().yolo_cast_f32_to_bf16(_p(x), _p(y), n, _stream()), 'yolo_cast_f32_to_bf16')
 
 
-def sum_partials(partial, n, add, out):
-    check(_lib.load().yolo_sum_partials(_p(partial), n, _p(add), _p(out), _stream()), 'yolo_sum_partials')
+def sum_partials(partial, n, add, out, out_plain=None):
+    check(_lib.load().yolo_sum_partials(_p(partial), n, _p(add), _p(out), _p(out_plain), _stream()), 'yolo_sum_partials')
 
 
 # ---------------------------------------------------------------------------------------------------------------- launch sequencer

@@ -78,8 +78,7 @@ class FlatOptimizer(object):
 
     def finish(self, model):
         """reported loss = YOLOv3 loss + sum of L2 regularisers (what keras' compiled loss contains), from the ranges launched this step"""
-        ops.sum_partials(self.l2_partial, self._cursor, None, model.l2_value)
-        ops.sum_partials(self.l2_partial, self._cursor, model.loss_obj.total, model.loss_value)
+        ops.sum_partials(self.l2_partial, self._cursor, model.loss_obj.total, model.loss_value, out_plain=model.l2_value)
 
     def launch(self, model):
         """the whole update in one launch (hipGraph replay, tests); the training step launches it per gradient bucket (launch_range)"""
