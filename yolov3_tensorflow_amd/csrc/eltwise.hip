@@ -124,14 +124,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ scale, float* __restrict__ shift,
                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o) {
   const float* const src[2] = {psum, psq};
+  // the eight threads that finish a channel request its gamma / beta / moving statistics NOW: after the reduction those reads were a
+  // second memory round trip at the end of a launch whose length is nothing but round trips (28 such launches per step)
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  float g = 1.f, b = 0.f, mm0 = 0.f, mv0 = 0.f;
+  if ((threadIdx.x >> 3) == 0 && c < C) {
+    if (gamma) g = gamma[c];
+    if (beta) b = beta[c];
+    if (moving_mean) { mm0 = moving_mean[c]; mv0 = moving_var[c]; }
+  }
   double tot[2];
   if (!column_reduce<2>(src, P, rstride, C, tot)) return;
-  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   const double mean = tot[0] / (double)count;
   double var = tot[1] / (double)count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   const float sc = g * rstd;
   scale[c] = sc;
   shift[c] = b - (float)mean * sc;
@@ -139,8 +146,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   rstd_o[c] = rstd;
   if (moving_mean) {
     const double unb = count > 1.f ? var * ((double)count / ((double)count - 1.0)) : var;
-    moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
-    moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unb;
+    moving_mean[c] = momentum * mm0 + (1.f - momentum) * (float)mean;
+    moving_var[c] = momentum * mv0 + (1.f - momentum) * (float)unb;
   }
 }
 
