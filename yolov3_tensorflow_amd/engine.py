@@ -210,6 +210,7 @@ class Graph(object):
         self._wgrad_cost, self.wgrad_cost_limit = 0.0, 18.0   # ... or as soon as the pending ones reach this many GFLOP (a big 3x3 layer goes alone)
         self.bucket_cut, self.bucket_offset, self.on_bucket = -1, 0, None
         self.buckets, self.bucket_tail = [], None
+        self.tail_on_main = False          # set by the owner (single GPU, per-bucket updates): see bucket_done
 
     # ------------------------------------------------------------------------------------------------ allocation helpers
     def _buffer(self, shape, dtype=None):
@@ -515,8 +516,8 @@ class Graph(object):
             f()
             if i in cuts:
                 self.bucket_done(*cuts[i])
-        self.bucket_done(*self.bucket_ranges[-1])
-        if side is not None:
+        self.bucket_done(*self.bucket_ranges[-1], last=True)
+        if side is not None and not self.tail_on_main:
             self.stream_wait(torch.cuda.current_stream(self.dev), side)
 
     def stream_wait(self, waiter, signaler):
@@ -532,13 +533,24 @@ class Graph(object):
         if n:
             ops.wgrad_reduce_batched(tab, n, blocks, self.slab_arena, self.ps.grad)
 
-    def bucket_done(self, lo, hi):
+    def bucket_done(self, lo, hi, last=False):
         """every gradient of the parameter range [lo, hi) has been enqueued (main stream: BatchNorm gradients; weight-gradient stream: the
         slab passes).  Hand what is pending to the weight-gradient stream together with the ONE launch that sums the bucket's slabs, then
-        tell the owner (gradient exchange and / or the optimizer launch of this bucket, both behind that launch on the side stream)"""
+        tell the owner (gradient exchange and / or the optimizer launch of this bucket, both behind that launch on the side stream).
+
+        The LAST range of a step (stem + stride-4 stage: nothing is left to overlap it with) with ``tail_on_main``: the main stream joins the
+        weight-gradient stream once and runs the slab sum -- and, through ``on_bucket(lo, hi, True)``, the owner's update -- itself: one
+        cross-stream hand-off at the end of the step instead of two (each costs 10-20 us of idle GPU on this runtime)"""
+        if last and self.tail_on_main and self.wgrad_stream is not None:
+            self.flush_wgrad()
+            self.stream_wait(torch.cuda.current_stream(self.dev), self.wgrad_stream)
+            self.reduce_slabs(lo, hi)
+            if self.on_bucket is not None:
+                self.on_bucket(lo, hi, True)
+            return
         self.on_wgrad_stream(lambda: self.reduce_slabs(lo, hi), flush=True)
         if self.on_bucket is not None:
-            self.on_bucket(lo, hi)
+            self.on_bucket(lo, hi, False)
 
     def owned_tensors(self):
         """every device tensor this graph (its parameter store, ops and BatchNorm states) holds"""

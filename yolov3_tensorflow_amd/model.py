@@ -175,7 +175,7 @@ class YOLOv3Model(object):
             with torch.cuda.stream(cs):
                 self.optimizer.launch_range(self, lo, hi, first)
 
-    def _bucket_ready(self, lo, hi):
+    def _bucket_ready(self, lo, hi, on_main=False):
         """engine callback (eager mode): the gradient range [lo, hi) is complete behind what is queued on the main and weight-gradient
         streams.  Data parallel: all-reduce it, then update it, on the communication stream; single GPU: update it on the weight-gradient
         stream.  Either way the bucket's RAdam + L2 launch overlaps the rest of the backward pass (reference north_star: all-reduce of
@@ -185,7 +185,7 @@ class YOLOv3Model(object):
             self._allreduce_bucket(lo, hi, then_update=True, first=first)
             return
         side = self.g.wgrad_stream
-        if side is None:
+        if side is None or on_main:                 # (on_main: the step's last range, already behind the weight-gradient stream: engine.bucket_done)
             self.optimizer.launch_range(self, lo, hi, first)
         else:
             with torch.cuda.stream(side):
@@ -222,14 +222,16 @@ class YOLOv3Model(object):
                 try:
                     self._step_ranges = []
                     g.on_bucket = self._bucket_ready
+                    tail = g.tail_on_main = not dp and g.wgrad_stream is not None and os.environ.get('YOLO_TAIL_ON_MAIN', '1') != '0'
                     try:
                         self._fwd_bwd()
                     finally:
                         g.on_bucket = None
+                        g.tail_on_main = False
                     main = torch.cuda.current_stream(self.device)
                     if self._comm_stream is not None and dp:
                         g.stream_wait(main, self._comm_stream)
-                    if g.wgrad_stream is not None:
+                    if g.wgrad_stream is not None and not tail:     # (tail: the main stream joined the side stream before the last range)
                         g.stream_wait(main, g.wgrad_stream)
                     covered = sum(hi - lo for lo, hi in self._step_ranges)
                     if covered != g.ps.n:
