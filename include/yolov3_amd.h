@@ -95,6 +95,13 @@ int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* sr
 /* dx[N,H,W,Cin] (=|+=) conv_transpose(dy[N,Ho,Wo,Cout], w).  Cin must be a multiple of 64.  accumulate != 0 adds into dx. */
 int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate,
                       void* stream);
+/* accumulate = 2 (yolo_conv2d_dgrad / _bn, 3x3 stride-2 problems run as four parity classes: yolo_conv2d_dgrad_classed(p) != 0): only the
+ * even / even positions of dx hold a previous contribution -- the one a 1x1 stride-2 shortcut convolution's data gradient wrote with
+ * yolo_conv2d_dgrad_even, which touches dx[:, ::2, ::2, :] only (the reference's down-sampling blocks: resnet18.py:31-52 feed one tensor to
+ * a 3x3 / stride-2 and a 1x1 / stride-2 convolution; TF adds the two gradients densely).  Three quarters of the shortcut gradient are
+ * structural zeros: they are neither written nor read back. */
+int yolo_conv2d_dgrad_classed(const yolo_conv_problem* p);
+int yolo_conv2d_dgrad_even(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, void* stream);
 /* dx = addend + conv_transpose(dy, w): accumulate = 1 with the other contribution left where it was produced (no copy into dx first). */
 int yolo_conv2d_dgrad_add(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, const void* addend, void* stream);
 /* The same with the BatchNorm-backward REDUCE of the unit whose output gradient dx is, in the epilogue (the reference differentiates

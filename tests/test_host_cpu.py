@@ -72,7 +72,7 @@ def mocked_kernels(monkeypatch):
         fn = getattr(ops, name)
         if callable(fn) and getattr(fn, '__module__', None) == ops.__name__ and name not in (
                 'same_pad', 'conv_problem', 'mix_problem', 'pad_channels', 'make_loss_config', 'conv2d_stat_rows', 'reduce_rows', 'radam_l2_blocks',
-                'loss_workspace_bytes', 'check', '_p', '_stream', 'conv2d_wgrad_workspace_bytes', 'conv2d_wgrad_splits', 'conv2d_dgrad_bn_rows', 'stem_pool_bwd_slabs', 'reduce_blocks', 'bn_bwd_fused_workspace_floats', 'bn_bwd_fused_sync_words', 'dwconv_mix_wgrad_workspace_bytes'):
+                'loss_workspace_bytes', 'check', '_p', '_stream', 'conv2d_wgrad_workspace_bytes', 'conv2d_wgrad_splits', 'conv2d_dgrad_bn_rows', 'conv2d_dgrad_classed', 'stem_pool_bwd_slabs', 'reduce_blocks', 'bn_bwd_fused_workspace_floats', 'bn_bwd_fused_sync_words', 'dwconv_mix_wgrad_workspace_bytes'):
             monkeypatch.setattr(ops, name, (lambda n: (lambda *a, **k: calls.append(n)))(name))
     monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
     monkeypatch.setattr(torch.cuda, 'current_device', lambda: 0)
@@ -137,6 +137,17 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
     assert c['bn_act_bwd_reduce'] == len([op for op in units if op.producer is None and (op.m_bn is not None or op.o_bn is not None)])
     n_alias = sum(1 for op in units if op.skip_dres)
     assert backbone != 'resnet-18' or n_alias == 4, n_alias          # the second block of each stage has the identity shortcut
+    # down-sampling blocks: the 1x1 / stride-2 shortcut's data gradient writes the even / even positions only, the 3x3 / stride-2 one
+    # accumulates onto that parity class alone
+    sparse = [op for op in m.g.tape if isinstance(op, engine.ConvOp) and op.even_only]
+    assert len(sparse) == (3 if backbone != 'mixnet-18' else len(sparse))       # the shortcuts of the three down-sampling stages
+    for op in sparse:
+        w = op.y.x.grad_writers
+        i = w.index(op)
+        if op.acc == [False]:                   # first writer: its 3x3 partner covers the rest of the tensor
+            assert w[i + 1].acc == [2] and w[i + 1].y.p.R == 3 and w[i + 1].y.p.stride == 2
+        else:                                   # (the stage outputs that also feed the FPN heads: the head's gradient arrives first)
+            assert i > 0 and op.acc == [True]
     for op in m.g.tape:
         if isinstance(op, engine.ConvOp) and op.addend is not None:
             assert op.acc == [True] and any(u.skip_dres and u.out is op.addend for u in units)

@@ -411,6 +411,56 @@ def test_stride2_dgrad_parity_classes_match_strided_gather(dev, shape):
         torch.testing.assert_close(a, b, rtol=2 ** -7, atol=2e-3)
 
 
+@pytest.mark.parametrize('shape', [(2, 52, 52, 64, 128), (3, 26, 30, 128, 256), (1, 27, 25, 64, 64)], ids=str)
+def test_downsampling_block_input_gradient_sparse_shortcut(dev, shape):
+    """the input gradient of a down-sampling block = data gradient of its 1x1 / stride-2 shortcut + data gradient of its 3x3 / stride-2
+    convolution.  Dense form: the shortcut's gradient written everywhere (zeros at three quarters of the positions), the 3x3 one accumulated
+    onto it.  Sparse form: conv2d_dgrad(even_only=True) touches the even / even positions only and the 3x3 launch accumulates onto that
+    parity class alone (accumulate=2) -- the same bits, on a buffer that starts as NaN; with and without the BatchNorm reduce epilogue"""
+    from yolov3_tensorflow_amd import ops
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(H * 31 + W)
+    p3 = ops.conv_problem(N, H, W, Cin, Cout, 3, 2, 'same')
+    p1 = ops.conv_problem(N, H, W, Cin, Cout, 1, 2, 'same')
+    assert ops.conv2d_dgrad_classed(p3) and not ops.conv2d_dgrad_classed(p1) and (p1.Ho, p1.Wo) == (p3.Ho, p3.Wo)
+    w3 = bf(torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).to(dev)
+    w1 = bf(torch.randn(Cout, 1, 1, Cin, generator=g) * 0.1).to(dev)
+    w3d = torch.empty(Cin, 3, 3, Cout, dtype=ACT(), device=dev)
+    w1d = torch.empty(Cin, 1, 1, Cout, dtype=ACT(), device=dev)
+    ops.repack_dgrad_weights(w3, w3d, Cout, 3, 3, Cin)
+    ops.repack_dgrad_weights(w1, w1d, Cout, 1, 1, Cin)
+    dy3 = bf(torch.randn(N, p3.Ho, p3.Wo, Cout, generator=g)).to(dev)
+    dy1 = bf(torch.randn(N, p3.Ho, p3.Wo, Cout, generator=g)).to(dev)
+    M = N * H * W
+    y = bf(torch.randn(M, Cin, generator=g)).to(dev)
+    mean, rstd = (torch.randn(Cin, generator=g) * 0.2).to(dev), (torch.rand(Cin, generator=g) + 0.5).to(dev)
+    mask = torch.randint(0, 256, (M * Cin // 8,), generator=g, dtype=torch.uint8).to(dev)
+    rows = ops.conv2d_dgrad_bn_rows(p3)
+    for fused in (False, True):
+        res = []
+        for sparse in (False, True):
+            dx = torch.full((N, H, W, Cin), float('nan'), dtype=ACT(), device=dev)
+            ops.conv2d_dgrad(p1, dy1, w1d, dx, even_only=sparse)
+            part = torch.zeros(rows, 3, Cin, device=dev)
+            kw = dict(bn=dict(mask=mask, y=y, mean=mean, rstd=rstd, partial=part)) if fused else {}
+            ops.conv2d_dgrad(p3, dy3, w3d, dx, accumulate=2 if sparse else True, **kw)
+            torch.cuda.synchronize()
+            res.append((dx.clone(), part.clone()))
+        assert torch.isfinite(res[1][0].float()).all()
+        assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16))
+        assert torch.equal(res[0][1], res[1][1])
+    # the even-only launch by itself: the dense gradient at the even / even positions, nothing elsewhere
+    dense = torch.empty(N, H, W, Cin, dtype=ACT(), device=dev)
+    ops.conv2d_dgrad(p1, dy1, w1d, dense)
+    sparse = torch.full((N, H, W, Cin), 7.0, dtype=ACT(), device=dev)
+    ops.conv2d_dgrad(p1, dy1, w1d, sparse, even_only=True)
+    torch.cuda.synchronize()
+    assert torch.equal(sparse[:, ::2, ::2].float(), dense[:, ::2, ::2].float())
+    keep = torch.ones(H, W, dtype=torch.bool, device=dev)
+    keep[::2, ::2] = False
+    assert bool((sparse[:, keep].float() == 7.0).all()) and float(dense[:, keep].float().abs().max()) == 0.0
+
+
 def test_conv_fused_upsample_concat(dev):
     """1x1 conv over concat(upsample2x(a), b) without materialising the concat (yolov3_detector.py:115-118)"""
     from yolov3_tensorflow_amd import ops

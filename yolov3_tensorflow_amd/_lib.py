@@ -63,6 +63,8 @@ SIGNATURES = {
     'yolo_conv2d_dgrad_bn_rows': (I, [CP]),
     'yolo_conv2d_dgrad_bn': (I, [CP, P, P, P, I, P, P, P, P, P, P, P, P, P, P]),
     'yolo_conv2d_dgrad_add': (I, [CP, P, P, P, P, P]),
+    'yolo_conv2d_dgrad_classed': (I, [CP]),
+    'yolo_conv2d_dgrad_even': (I, [CP, P, P, P, I, P]),
     'yolo_conv2d_wgrad': (I, [CP, P, P, P, P, I, P]),
     'yolo_conv2d_wgrad_workspace_bytes': (C.c_size_t, [CP]),
     'yolo_conv2d_wgrad_reduce': (I, [CP, P, P, P, P, P, C.c_size_t, I, P]),

@@ -37,6 +37,7 @@ struct Gather {
   // stride-1 correlation over dY with 1 or 2 of the 3 taps per dimension, written to every other row / column of dX; the kernel
   // specialises its copy of this struct per class (s2 == 0: everything below is unused)
   int s2;
+  int s2_ny;           // classes launched (grid y): 4, or 1 = only the even / even class (1x1 stride-2: the other positions get nothing)
   int N, S_full;       // images; tap columns of the (flipped) weight tensor
   int wKg;             // weight row stride in elements (9 * C)
   struct Dim { int n, pad, size, t0, t1; } rowd[2], cold[2];   // per parity: taps, padding, class grid size, flipped tap indices
@@ -494,7 +495,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_fwd_kernel(Gather g, const bf16
   }
 
   // (partial row of a fused BatchNorm reduce: one per pixel tile and parity class; classes smaller than the grid leave theirs untouched = 0)
-  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, OUT_F32, BNEPI>(acc, smem, g.M, m0, n0, tile_m, bias, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane, wm, wn,
+  // accumulate == 2: only the even / even parity class has a previous contribution (a 1x1 stride-2 gradient written at those positions only)
+  const int acc_eff = accumulate == 2 ? ((cv.on && cv.ph == 0 && cv.pw == 0) ? 1 : 0) : accumulate;
+  tile_epilogue<BM, BN, NW, WM, WN, PT, CT, OUT_F32, BNEPI>(acc, smem, g.M, m0, n0, tile_m, bias, Yv, ldy, acc_eff, stat_sum, stat_sq, Kout, tid, lane, wm, wn,
                                                      cv, bnepi, (int)(blockIdx.y * (gridDim.x / tiles_n)) + tile_m);
 }
 
@@ -1408,7 +1411,7 @@ int launch_tile3_e(const Gather& g, const void* w, const float* bias, void* y, i
     if (e != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW, BNEPI>), dim3(tiles_m * tn, g.s2 ? 4 : 1), dim3(NW * 64), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
+  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, NS, F32, FAST, NW, BNEPI>), dim3(tiles_m * tn, g.s2 ? g.s2_ny : 1), dim3(NW * 64), lds, st, g, (const bf16_t*)w, bias, y, ldy, accumulate,
                      e.ssum, e.ssq, Kout, tn, e.bn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
@@ -1515,7 +1518,7 @@ extern "C" int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, con
 
 namespace {
 // conv-transpose as a forward gather over dy with flipped taps: src = (row - (R-1-pad) + tap') / stride
-int dgrad_gather(const yolo_conv_problem* p, const void* dy, Gather* gp) {
+int dgrad_gather(const yolo_conv_problem* p, const void* dy, Gather* gp, bool even_only = false) {
   int rc = check_problem(p);
   if (rc) return rc;
   YOLO_CHECK_ARG(p->Cin % 64 == 0, "dgrad needs Cin % 64 == 0");
@@ -1528,19 +1531,24 @@ int dgrad_gather(const yolo_conv_problem* p, const void* dy, Gather* gp) {
   g.smul = 1; g.pad_h = p->R - 1 - p->pad_t; g.pad_w = p->S - 1 - p->pad_l; g.den = p->stride;
   g.M = p->N * p->H * p->W; g.Kg = p->R * p->S * p->Cout;
   g.rhw = 1.0f / (float)(g.Ho * g.Wo); g.rw = 1.0f / (float)g.Wo; g.magicS = 65536 / g.S + 1;
-  g.s2 = 0; g.N = p->N; g.S_full = p->S; g.wKg = g.Kg; g.OH = p->H; g.OW = p->W;
+  g.s2 = 0; g.s2_ny = 4; g.N = p->N; g.S_full = p->S; g.wKg = g.Kg; g.OH = p->H; g.OW = p->W;
   YOLO_CHECK_ARG(g.M < (1 << 24), "row decode needs N*H*W < 2^24");
-  if (g_s2_classes && p->stride == 2 && p->R == 3 && p->S == 3 && p->H >= 2 && p->W >= 2 && p->Cout % 64 == 0) {
+  const bool k3 = p->R == 3 && p->S == 3;
+  const bool k1 = even_only && p->R == 1 && p->S == 1 && p->pad_t == 0 && p->pad_l == 0;
+  YOLO_CHECK_ARG(!even_only || (k1 && p->stride == 2 && p->Cout % 64 == 0), "even-only data gradient: 1x1, stride 2, no padding, Cout % 64 == 0");
+  if ((g_s2_classes || k1) && p->stride == 2 && (k3 || k1) && p->H >= 2 && p->W >= 2 && p->Cout % 64 == 0) {
     // dX[h] = sum_r dY[(h + pad - r) / 2] W[r] over the r with (h + pad - r) even: for h = 2h' + ph the taps r = (ph + pad) mod 2 (+ 2),
     // taken in descending r (= ascending flipped index R-1-r) they read dY rows h' - pad', h' - pad' + 1: a stride-1 correlation.
     // The strided gather (den = 2) instead walks all 9 taps and fetches zeros for 27 of every 36 (pixel, tap) pairs.
-    auto dim = [](int pad, int size, Gather::Dim (&d)[2]) {
+    // (1x1: the even / even class has its one tap, the other three have none -- only that class is launched)
+    const int R = p->R;
+    auto dim = [R](int pad, int size, Gather::Dim (&d)[2]) {
       for (int par = 0; par < 2; ++par) {
-        const int r_lo = (par + pad) & 1;                // taps r_lo, r_lo + 2 (< 3)
-        const int r_hi = r_lo + 2 < 3 ? r_lo + 2 : r_lo;
-        d[par].n = r_hi > r_lo ? 2 : 1;
-        d[par].t0 = 2 - r_hi;                            // flipped index of the first (largest r) tap
-        d[par].t1 = 2 - r_lo;
+        const int r_lo = (par + pad) & 1;                // taps r_lo, r_lo + 2 (< R)
+        const int r_hi = r_lo + 2 < R ? r_lo + 2 : r_lo;
+        d[par].n = r_lo < R ? (r_hi > r_lo ? 2 : 1) : 0;
+        d[par].t0 = R - 1 - r_hi;                        // flipped index of the first (largest r) tap
+        d[par].t1 = R - 1 - r_lo;
         d[par].pad = -((par + pad - r_hi) / 2);          // (par + pad - r_hi) is even and <= 0
         d[par].size = (size - par + 1) / 2;
       }
@@ -1548,6 +1556,7 @@ int dgrad_gather(const yolo_conv_problem* p, const void* dy, Gather* gp) {
     dim(p->pad_t, p->H, g.rowd);
     dim(p->pad_l, p->W, g.cold);
     g.s2 = 1;
+    g.s2_ny = k1 ? 1 : 4;
     g.wKg = g.Kg;
     g.M = p->N * g.rowd[0].size * g.cold[0].size;        // the largest class: tile choice and grid size
     g.den = 1;
@@ -1562,7 +1571,27 @@ extern "C" int yolo_conv2d_dgrad(const yolo_conv_problem* p, const void* dy, con
   Gather g;
   int rc = dgrad_gather(p, dy, &g);
   if (rc) return rc;
+  YOLO_CHECK_ARG(accumulate != 2 || (g.s2 && g.s2_ny == 4), "accumulate = 2 needs the parity-class data gradient (yolo_conv2d_dgrad_classed)");
   return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate, Epi{}, p->Cin, (hipStream_t)stream);
+}
+
+// 1x1 / stride-2 data gradient that writes ONLY the positions it contributes to, dx[:, ::2, ::2, :] (=|+=): the other three quarters of dx
+// receive nothing from this layer.  For the first writer of a fan-in whose other writer is a 3x3 stride-2 data gradient launched with
+// accumulate = 2 (previous contribution at the even / even positions only): neither the zeros of this layer nor their read-back happen.
+extern "C" int yolo_conv2d_dgrad_even(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, void* stream) {
+  YOLO_CHECK_ARG(dy && w_dgrad && dx, "null pointer");
+  Gather g;
+  int rc = dgrad_gather(p, dy, &g, true);
+  if (rc) return rc;
+  return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate ? 1 : 0, Epi{}, p->Cin, (hipStream_t)stream);
+}
+
+// 1 if yolo_conv2d_dgrad runs this problem as parity classes (3x3, stride 2): accumulate = 2 is accepted then
+extern "C" int yolo_conv2d_dgrad_classed(const yolo_conv_problem* p) {
+  Gather g;
+  static const char dummy = 0;
+  if (!p || dgrad_gather(p, &dummy, &g)) return 0;
+  return g.s2 && g.s2_ny == 4 ? 1 : 0;
 }
 
 // dx = addend + conv_transpose(dy, w): the fan-in add of yolo_conv2d_dgrad(accumulate = 1) with the other contribution read from ITS buffer
@@ -1609,7 +1638,8 @@ extern "C" int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, 
   e.bn.y2 = (const bf16_t*)y2; e.bn.mean2 = mean2; e.bn.rstd2 = rstd2;
   e.bn.partial = partial;
   e.bn.addend = (const bf16_t*)addend;             // non-null: the fan-in source instead of dx itself (implies accumulate)
-  return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, (accumulate || addend) ? 1 : 0, e, p->Cin, (hipStream_t)stream);
+  YOLO_CHECK_ARG(accumulate != 2 || (g.s2 && g.s2_ny == 4 && !addend), "accumulate = 2 needs the parity-class data gradient and no addend");
+  return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate == 2 ? 2 : ((accumulate || addend) ? 1 : 0), e, p->Cin, (hipStream_t)stream);
 }
 
 namespace {

@@ -448,6 +448,26 @@ class Graph(object):
             for op in self.tape:
                 if isinstance(op, ApplyOp) and os.environ.get('YOLO_SHORTCUT_ALIAS', '1') != '0':
                     op.plan_shortcut_alias()
+        # down-sampling blocks: one tensor feeds a 1x1 / stride-2 shortcut convolution and a 3x3 / stride-2 convolution.  The shortcut's
+        # data gradient is zero at three quarters of the positions: it writes the even / even ones only, and the 3x3 gradient (four parity
+        # classes) accumulates onto that class alone (YOLO_S2_SPARSE=0 for A/B runs)
+        if os.environ.get('YOLO_S2_SPARSE', '1') != '0':
+            for v in self.vals_with_writers():
+                w = v.grad_writers
+                for i, a in enumerate(w):
+                    if not (isinstance(a, ConvOp) and a.y.x is v):
+                        continue
+                    pa = a.y.p
+                    if not (pa.R == 1 and pa.S == 1 and pa.stride == 2 and pa.pad_t == 0 and pa.pad_l == 0 and pa.Cout % 64 == 0):
+                        continue
+                    if a.acc == [True]:                    # adds onto an earlier (dense) contribution: only where it has one of its own
+                        a.even_only = True
+                    elif a.acc == [False] and i + 1 < len(w):
+                        b = w[i + 1]                       # first writer: the next one must write the other three quarters itself
+                        if (isinstance(b, ConvOp) and b.y.x is v and b.acc == [True] and b.addend is None and
+                                ops.conv2d_dgrad_classed(b.y.p)):
+                            a.even_only = True
+                            b.acc = [2]
         # gradient buckets for data-parallel overlap, by backbone stage (parameters are laid out in creation order, backward runs in reverse):
         #   [first stride-32 conv, n)   module512 + the three heads, ~70 % of the parameters: complete ~40 % into the backward pass
         #   [first stride-8 conv, that) the stride-8 / stride-16 stages
@@ -482,6 +502,16 @@ class Graph(object):
                     rows.append([op.y.wp.offset // 4, op.slab_off // 4, n4, op.splits, blocks])
                     blocks += ops.reduce_blocks(n4, op.splits)
             self.reduce_tables[(lo, hi_)] = (torch.tensor(rows, dtype=torch.int64, device=dev) if rows else None, len(rows), blocks)
+
+    def vals_with_writers(self):
+        """every activation value some backward op writes a gradient into"""
+        seen, out = set(), []
+        for op in self.tape:
+            for v in (getattr(op, 'out', None), getattr(getattr(op, 'y', None), 'x', None)):
+                if v is not None and id(v) not in seen and getattr(v, 'grad_writers', None):
+                    seen.add(id(v))
+                    out.append(v)
+        return out
 
     def refresh_dgrad_weights(self):
         """flipped/transposed bf16 weight copies for the data-gradient pass, all layers in one launch"""
@@ -674,6 +704,7 @@ class ConvOp(object):
         self.acc = []
         self.bn_epi = None          # set by ApplyOp.plan_fusion: this data gradient completes a BatchNorm unit's output gradient
         self.addend = None          # set by ApplyOp.plan_shortcut_alias: the fan-in contribution is read from that Val's .grad
+        self.even_only = False      # set by Graph.finalize: 1x1 / stride-2 shortcut whose gradient is written at the even / even positions only
         if not self.needs_dgrad():
             return
         x = y.x
@@ -716,7 +747,7 @@ class ConvOp(object):
             ops.upcat_split_bwd(self.dcat, a.grad, self.acc[0], b.grad, self.acc[1], N, H, W, a.shape[3], b.shape[3])
         else:
             ops.conv2d_dgrad(y.p, y.dy, self.w_dg, x.grad, accumulate=self.acc[0], bn=self.bn_epi,
-                             addend=None if self.addend is None else self.addend.grad)
+                             addend=None if self.addend is None else self.addend.grad, even_only=self.even_only)
 
 
 class MixConvOp(object):

@@ -57,10 +57,14 @@ def conv2d_fwd(p, src1, w_fwd, y, src0=None, bias=None, stat_sum=None, stat_sq=N
                                       1 if y.dtype == torch.float32 else 0, _p(stat_sum), _p(stat_sq), _stream()), 'yolo_conv2d_fwd')
 
 
-def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False, bn=None, addend=None):
+def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False, bn=None, addend=None, even_only=False):
     """``bn`` = dict(mask, y, mean, rstd, partial[, y2, mean2, rstd2]): dx is the output gradient of a BatchNorm unit -- leave the masked
     gradient in dx and the unit's backward partial sums in ``partial`` (yolo_conv2d_dgrad_bn).  ``addend``: dx = addend + gradient
-    (the fan-in add with the other contribution read from its own buffer)"""
+    (the fan-in add with the other contribution read from its own buffer).  ``accumulate`` = 2: only the even / even positions hold a previous
+    contribution (3x3 stride-2 problems); ``even_only``: a 1x1 stride-2 gradient that writes just those positions (yolo_conv2d_dgrad_even)"""
+    if even_only:
+        check(_lib.load().yolo_conv2d_dgrad_even(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _stream()), 'yolo_conv2d_dgrad_even')
+        return
     if bn is None:
         if addend is not None:
             check(_lib.load().yolo_conv2d_dgrad_add(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), _p(addend), _stream()), 'yolo_conv2d_dgrad_add')
@@ -70,6 +74,11 @@ def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False, bn=None, addend=None):
     check(_lib.load().yolo_conv2d_dgrad_bn(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _p(addend), _p(bn.get('mask')), _p(bn['y']),
                                            _p(bn['mean']), _p(bn['rstd']), _p(bn.get('y2')), _p(bn.get('mean2')), _p(bn.get('rstd2')),
                                            _p(bn['partial']), _stream()), 'yolo_conv2d_dgrad_bn')
+
+
+def conv2d_dgrad_classed(p):
+    """True if conv2d_dgrad runs this problem as four parity classes (3x3, stride 2): accumulate = 2 is accepted then"""
+    return bool(_lib.load().yolo_conv2d_dgrad_classed(C.byref(p)))
 
 
 def conv2d_dgrad_bn_rows(p):
