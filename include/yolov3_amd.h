@@ -159,6 +159,14 @@ int yolo_bn_stats(const void* x, int M, int C, float* partial, void* stream);
 int yolo_bn_finalize(const float* psum, const float* psq, int P, int64_t row_stride, int C, float count, const float* gamma,
                      const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* scale,
                      float* shift, float* mean, float* rstd, void* stream);
+/* Small maps (a few hundred partial rows): yolo_bn_finalize + yolo_bn_act_fwd (out = act(y*scale + shift + res), relu_mask as
+ * yolo_bn_act_fwd_mask, NULL = none) in ONE launch -- each of the two is nothing but the ~5 us floor of a dependent launch there.
+ * Every workgroup reduces the partial rows of its 32 channels itself, so P should stay below a few hundred; C % 32 == 0; gamma / beta
+ * are required.  Replaces the BatchNormalization + Activation(+ add) pair of reference backbone/basic_backbone.py:68-90,102-125. */
+int yolo_bn_finalize_act_fwd(const float* psum, const float* psq, int P, int64_t row_stride, int C, float count, const float* gamma,
+                             const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* scale,
+                             float* shift, float* mean, float* rstd, const void* y, const void* res, void* out, uint8_t* relu_mask,
+                             int64_t M, int relu, void* stream);
 /* The same finalize for up to 4 BatchNorms over consecutive channel groups of ONE tensor (MixNet's grouped BN: shared statistics work
  * vectors, separate gamma / beta / moving statistics / gradient slots): split[0..ngroups] (host) = group boundaries, the pointer arrays
  * (host arrays of device pointers) have ngroups entries.  One launch instead of one per group. */
@@ -187,6 +195,12 @@ int yolo_bn_act_bwd_reduce(const void* dout, const void* out, int relu, const vo
  * channel sub-range): dgamma = sum g*xhat, dbeta = sum g (NULL = skip), k1 = dbeta/count, k2 = dgamma/count; which = 1 (y) or 2 (y2) */
 int yolo_bn_bwd_finalize(const float* partial, int P, int64_t row_stride, int64_t q_stride, int C, int which, float count,
                          float* dgamma, float* dbeta, float* k1, float* k2, void* stream);
+/* Small maps: yolo_bn_bwd_finalize (which = 1) + yolo_bn_act_bwd_apply on an already masked gradient g (relu = 0), in ONE launch:
+ * dgamma / dbeta (NULL = skip), k1, k2 from the [P][..] partial rows, then dy (=|+=) a1*(g - k1 - xhat*k2) and the optional shortcut
+ * copy dres (=|+=) g.  C % 32 == 0.  (TF autodiff of the same reference lines.) */
+int yolo_bn_bwd_finalize_apply(const float* partial, int P, int64_t row_stride, int64_t q_stride, int C, float count, float* dgamma,
+                               float* dbeta, float* k1, float* k2, const void* g, const void* y, const float* a1, const float* mean,
+                               const float* rstd, void* dy, int acc_dy, void* dres, int acc_dres, int64_t M, void* stream);
 /* dy (=|+=) a1*(g - k1 - xhat*k2) (a1 NULL: dy = g); optional second BN branch -> dy2; optional dres (=|+=) g */
 int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu, const void* y, const float* a1, const float* mean,
                           const float* rstd, const float* k1, const float* k2, void* dy, int acc_dy, const void* y2, const float* a2,

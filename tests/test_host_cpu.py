@@ -116,7 +116,12 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
     assert c['stem_pool_bwd_wgrad'] == 1 and c['bn_pool_bwd_apply'] == 0
     assert 1 <= c['wgrad_reduce_batched'] <= 3 and c['conv2d_wgrad_reduce'] == 0        # one slab-summing launch per gradient bucket
     assert c['loss_fwd_bwd'] == 1 and c['radam_l2_step'] == 1 and c['radam_schedule'] == 1 and c['upcat_split_bwd'] == 2
-    assert c['bn_finalize'] + 4 * c['bn_finalize_grouped'] == n_bn      # MixNet: one grouped launch per 4 group BatchNorms
+    from yolov3_tensorflow_amd import engine
+    # (small maps -- every map of this 96 x 96 input -- run finalize + apply as ONE launch where the unit has a single plain BatchNorm)
+    assert c['bn_finalize'] + c['bn_finalize_act_fwd'] + 4 * c['bn_finalize_grouped'] == n_bn      # MixNet: one grouped launch per 4 group BatchNorms
+    assert c['bn_finalize_act_fwd'] + c['bn_act_fwd'] == len([op for op in m.g.tape if isinstance(op, engine.ApplyOp)])
+    assert c['bn_finalize_act_fwd'] > 0 and c['bn_bwd_finalize_apply'] > 0
+    assert c['bn_bwd_finalize_apply'] + c['bn_act_bwd_apply'] <= c['bn_finalize_act_fwd'] + c['bn_act_fwd']
     if n_dw:
         assert c['dwconv_mix_fwd'] == 8 and c['dwconv_mix_dgrad'] == 8 and c['dwconv_mix_wgrad'] == 8
     # backward plan of the BatchNorm units: the data gradient that writes a unit's output gradient LAST carries its reduce (every unit whose

@@ -595,6 +595,92 @@ def test_bn_act_fwd_bwd(dev, mode):
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize('M,C,P,res', [(32 * 13 * 13, 512, 85, True), (32 * 26 * 26, 256, 338, False), (700, 32, 3, True), (5, 64, 1, False),
+                                        (32 * 26 * 26, 128, 169, True)], ids=str)
+def test_small_map_finalize_plus_apply_in_one_launch(dev, M, C, P, res):
+    """yolo_bn_finalize_act_fwd == yolo_bn_finalize + yolo_bn_act_fwd (mask variant) and yolo_bn_bwd_finalize_apply == yolo_bn_bwd_finalize +
+    yolo_bn_act_bwd_apply on the same partial rows: identical activations / masks / gradients wherever the per-channel constants agree bit
+    for bit (they are column sums in double, summed in another order: 1e-6 relative at most), moving statistics updated once"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(M + C + P)
+    d = lambda t: t.to(dev)
+    y = d(bf(torch.randn(M, C, generator=g) * 1.5 + 0.3))
+    r = d(bf(torch.randn(M, C, generator=g))) if res else None
+    # partial rows as the convolution epilogue leaves them: per-tile sums of y and y^2 (tile = consecutive rows)
+    rows_per = (M + P - 1) // P
+    yf = y.float()
+    pad = torch.zeros(P * rows_per - M, C, device=dev)
+    yt = torch.cat([yf, pad]).reshape(P, rows_per, C)
+    psum, psq = yt.sum(1).contiguous(), (yt * yt).sum(1).contiguous()
+    gamma, beta = d(torch.rand(C, generator=g) + 0.5), d(torch.randn(C, generator=g) * 0.2)
+    outs = []
+    for merged in (False, True):
+        mm, mv = d(torch.full((C,), 0.25)), d(torch.full((C,), 2.0))
+        sc, sh, mean, rstd = [torch.zeros(C, device=dev) for _ in range(4)]
+        out = torch.empty(M, C, dtype=ACT(), device=dev)
+        mask = torch.zeros(M * C // 8, dtype=torch.uint8, device=dev)
+        if merged:
+            ops.bn_finalize_act_fwd(psum.view(-1), psq.view(-1), P, C, C, M, gamma, beta, 1e-5, 0.9, mm, mv, sc, sh, mean, rstd, y, out, M, True,
+                                    res=r, mask=mask)
+        else:
+            ops.bn_finalize(psum.view(-1), psq.view(-1), P, C, C, M, gamma, beta, 1e-5, 0.9, mm, mv, sc, sh, mean, rstd)
+            ops.bn_act_fwd(y, sc, sh, out, M, C, True, res=r, mask=mask)
+        torch.cuda.synchronize()
+        outs.append((mm, mv, sc, sh, mean, rstd, out, mask))
+    a, b = outs
+    for u, v in zip(a[:6], b[:6]):
+        torch.testing.assert_close(u, v, rtol=2e-6, atol=1e-7)
+    same = ((a[2] == b[2]) & (a[3] == b[3]))                        # channels whose scale / shift came out bit-identical
+    assert same.float().mean() > 0.9
+    assert torch.equal(a[6][:, same], b[6][:, same])
+    torch.testing.assert_close(a[6].float(), b[6].float(), rtol=1e-2, atol=1e-2)
+    if bool(same.all()):
+        assert torch.equal(a[7], b[7])
+    # reference check of the merged launch on its own: float64 statistics of the stored values
+    m64, v64 = yf.double().mean(0), yf.double().var(0, unbiased=False)
+    torch.testing.assert_close(b[4].double(), m64, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(b[5].double(), 1.0 / torch.sqrt(v64 + 1e-5), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(b[0].double(), 0.9 * 0.25 + 0.1 * m64, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(b[1].double(), 0.9 * 2.0 + 0.1 * v64 * (M / max(M - 1.0, 1.0)), rtol=1e-5, atol=1e-6)
+
+    # backward: masked gradient g, partial rows [P][3][C] with quantities 0 (sum g) and 1 (sum g * xhat)
+    mean, rstd, scale = b[4], b[5], b[2]
+    gq = d(bf(torch.randn(M, C, generator=g)))
+    gq = torch.where(b[6] > 0, gq, torch.zeros_like(gq))
+    xhat = (yf - mean) * rstd
+    gt = torch.cat([gq.float(), pad]).reshape(P, rows_per, C)
+    xt = torch.cat([gq.float() * xhat, pad]).reshape(P, rows_per, C)
+    part = torch.zeros(P, 3, C, device=dev)
+    part[:, 0], part[:, 1] = gt.sum(1), xt.sum(1)
+    prev_dy = d(bf(torch.randn(M, C, generator=g)))
+    prev_dres = d(bf(torch.randn(M, C, generator=g)))
+    outs = []
+    for acc in (False, True):
+        pair = []
+        for merged in (False, True):
+            dg, db, k1, k2 = [torch.zeros(C, device=dev) for _ in range(4)]
+            dy = prev_dy.clone()
+            dres = prev_dres.clone() if res else None
+            if merged:
+                ops.bn_bwd_finalize_apply(part.view(-1), P, C, M, dg, db, k1, k2, gq, y, scale, mean, rstd, M, dy, acc_dy=acc, dres=dres,
+                                          acc_dres=acc)
+            else:
+                ops.bn_bwd_finalize(part.view(-1), P, C, 1, M, dg, db, k1, k2)
+                ops.bn_act_bwd_apply(gq, None, 0, M, C, y=y, a1=scale, mean=mean, rstd=rstd, k1=k1, k2=k2, dy=dy, acc_dy=acc, dres=dres,
+                                     acc_dres=acc)
+            torch.cuda.synchronize()
+            pair.append((dg, db, k1, k2, dy) + ((dres,) if res else ()))
+        u, v = pair
+        for i in range(4):       # (the two-launch finalize adds up to 3 rows per lane in float32 before widening when P > 128: 1e-7 of the partials)
+            torch.testing.assert_close(u[i], v[i], rtol=2e-5, atol=2e-5)
+        same = (u[2] == v[2]) & (u[3] == v[3])
+        assert same.float().mean() > (0.9 if P <= 128 else 0.3)
+        assert torch.equal(u[4][:, same], v[4][:, same])
+        torch.testing.assert_close(u[4].float(), v[4].float(), rtol=1e-2, atol=1e-2)
+        if res:
+            assert torch.equal(u[5], v[5])
+
+
 @pytest.mark.parametrize('M,Cc,mode', [(32 * 13 * 13, 512, 'plain'), (32 * 26 * 26, 256, 'res'), (32 * 52 * 52, 128, 'bn2'),
                                        (3001, 64, 'res_acc'), (32 * 104 * 104, 64, 'plain'), (32 * 104 * 104 * 2, 64, 'too_big')])
 @pytest.mark.parametrize('small_grid', [0, 128])

@@ -78,6 +78,8 @@ SIGNATURES = {
     'yolo_reduce_rows': (I, [I, I]),
     'yolo_bn_stats': (I, [P, I, I, P, P]),
     'yolo_bn_finalize': (I, [P, P, I, I64, I, F, P, P, F, F, P, P, P, P, P, P, P]),
+    'yolo_bn_finalize_act_fwd': (I, [P, P, I, I64, I, F, P, P, F, F, P, P, P, P, P, P, P, P, P, P, I64, I, P]),
+    'yolo_bn_bwd_finalize_apply': (I, [P, I, I64, I64, I, F, P, P, P, P, P, P, P, P, P, P, I, P, I, I64, P]),
     'yolo_bn_finalize_grouped': (I, [P, P, I, C.c_int64, I, C.c_float, I, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P]),
     'yolo_bn_bwd_finalize_grouped': (I, [P, I, C.c_int64, C.c_int64, I, I, C.c_float, I, P, P, P, P, P, P]),
     'yolo_bn_act_fwd': (I, [P, P, P, P, P, P, P, I64, I, I, P]),

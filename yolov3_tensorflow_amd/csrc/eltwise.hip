@@ -265,6 +265,199 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __
   }
 }
 
+// ---- small maps: finalize + apply in ONE launch -------------------------------------------------------------------------------------
+// On the 13 x 13 / 26 x 26 maps both launches of a BatchNorm (finalize: a few hundred partial rows; apply: a few MB) are nothing but the
+// ~5 us floor of a dependent launch.  Here a 1024-thread workgroup owns FM_CG channels and a slice of the rows: it first reduces the
+// partial rows of ITS channels (every row slice repeats that: P <= a few hundred rows, L2 hits), then applies.  The slice 0 workgroups
+// also publish the per-channel vectors the backward pass / the moving averages need.
+constexpr int FM_CG = 32, FM_RL = 1024 / FM_CG, FM_CV = FM_CG / 8;
+template <int K>
+__device__ __forceinline__ void group_reduce(const float* const (&src)[K], int P, size_t rstride, double (&tot)[K]) {
+  __shared__ double red[K][16][FM_CG];
+  const int c = threadIdx.x % FM_CG, rl = threadIdx.x / FM_CG;
+  double s[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) s[k] = 0.0;
+  int p = rl;
+  for (; p + 3 * FM_RL < P; p += 4 * FM_RL) {          // 4 K loads in flight
+    float f[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f[k][u] = src[k][(size_t)(p + u * FM_RL) * rstride + c];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] += ((double)f[k][0] + (double)f[k][1]) + ((double)f[k][2] + (double)f[k][3]);
+  }
+  for (; p < P; p += FM_RL) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] += (double)src[k][(size_t)p * rstride + c];
+  }
+  // a wave holds two row lanes of the 32 channels: one shuffle, then the 16 waves through LDS
+#pragma unroll
+  for (int k = 0; k < K; ++k) s[k] += __shfl_xor(s[k], 32, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < FM_CG) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[k][wave][lane] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < FM_CG) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) t += red[k][w][threadIdx.x];
+      tot[k] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_act_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int P,
+                                                               size_t rstride, int C, float count, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum,
+                                                               float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                               float* __restrict__ scale, float* __restrict__ shift,
+                                                               float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                               const bf16_t* __restrict__ y, const bf16_t* __restrict__ res,
+                                                               bf16_t* __restrict__ out, uint8_t* __restrict__ mask, int M, int rows_per,
+                                                               int relu) {
+  __shared__ float s_sc[FM_CG], s_sh[FM_CG];
+  const int c0 = blockIdx.x * FM_CG;
+  const int m_lo = blockIdx.y * rows_per, m_hi = min(M, m_lo + rows_per);
+  const int ch = threadIdx.x % FM_CV, r0 = threadIdx.x / FM_CV;
+  constexpr int RPP = 1024 / FM_CV;                    // rows per pass
+  // the first pass of the apply is requested before the reduction: its latency hides behind it
+  const size_t e0 = ((size_t)(m_lo + r0) * C + c0 + ch * 8);
+  uint4 yv0 = make_uint4(0u, 0u, 0u, 0u), rv0 = yv0;
+  if (m_lo + r0 < m_hi) { yv0 = ld16(y + e0); if (res) rv0 = ld16(res + e0); }
+  float g = 1.f, b = 0.f, mm0 = 0.f, mv0 = 0.f;
+  if (threadIdx.x < FM_CG) {
+    g = gamma[c0 + threadIdx.x];
+    b = beta[c0 + threadIdx.x];
+    if (moving_mean && blockIdx.y == 0) { mm0 = moving_mean[c0 + threadIdx.x]; mv0 = moving_var[c0 + threadIdx.x]; }
+  }
+  const float* const src[2] = {psum + c0, psq + c0};
+  double tot[2];
+  group_reduce<2>(src, P, rstride, tot);
+  if (threadIdx.x < FM_CG) {
+    const int c = c0 + threadIdx.x;
+    const double mean = tot[0] / (double)count;
+    double var = tot[1] / (double)count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = g * rstd, sh = b - (float)mean * sc;
+    s_sc[threadIdx.x] = sc;
+    s_sh[threadIdx.x] = sh;
+    if (blockIdx.y == 0) {
+      scale[c] = sc;
+      shift[c] = sh;
+      mean_o[c] = (float)mean;
+      rstd_o[c] = rstd;
+      if (moving_mean) {
+        const double unb = count > 1.f ? var * ((double)count / ((double)count - 1.0)) : var;
+        moving_mean[c] = momentum * mm0 + (1.f - momentum) * (float)mean;
+        moving_var[c] = momentum * mv0 + (1.f - momentum) * (float)unb;
+      }
+    }
+  }
+  __syncthreads();
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = s_sc[ch * 8 + j]; sh[j] = s_sh[ch * 8 + j]; }
+  for (int r = m_lo + r0; r < m_hi; r += RPP) {
+    const size_t e = (size_t)r * C + c0 + ch * 8;
+    uint4 yv = yv0, rv = rv0;
+    if (r != m_lo + r0) { yv = ld16(y + e); if (res) rv = ld16(res + e); }
+    float v[8];
+    unpack_bf8(yv, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+    if (res) {
+      float q[8];
+      unpack_bf8(rv, q);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += q[j];
+    }
+    if (relu) {
+      if (mask) {
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m |= (v[j] > 0.f ? 1u : 0u) << j;
+        mask[e >> 3] = (uint8_t)m;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st16(out + e, pack_bf8(v));
+  }
+}
+
+// backward twin: column sums of the [P][3][C] partial rows (quantities 0 and 1) -> dgamma, dbeta, k1, k2, then
+// dy (=|+=) a (g - k1 - xhat k2) and the optional shortcut copy dres (=|+=) g on the workgroup's row slice
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, int P, size_t rstride, size_t qstride,
+                                                                     int C, float count, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                     float* __restrict__ k1, float* __restrict__ k2,
+                                                                     const bf16_t* __restrict__ gin, const bf16_t* __restrict__ y,
+                                                                     const float* __restrict__ a1, const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd, bf16_t* __restrict__ dy, int acc_dy,
+                                                                     bf16_t* __restrict__ dres, int acc_dres, int M, int rows_per) {
+  __shared__ float s_k1[FM_CG], s_k2[FM_CG];
+  const int c0 = blockIdx.x * FM_CG;
+  const int m_lo = blockIdx.y * rows_per, m_hi = min(M, m_lo + rows_per);
+  const int ch = threadIdx.x % FM_CV, r0 = threadIdx.x / FM_CV;
+  constexpr int RPP = 1024 / FM_CV;
+  const size_t e0 = ((size_t)(m_lo + r0) * C + c0 + ch * 8);
+  uint4 gv0 = make_uint4(0u, 0u, 0u, 0u), yv0 = gv0;
+  if (m_lo + r0 < m_hi) { gv0 = ld16(gin + e0); yv0 = ld16(y + e0); }
+  float ca[8], cmu[8], crs[8];
+  ld8f(a1 + c0 + ch * 8, ca); ld8f(mean + c0 + ch * 8, cmu); ld8f(rstd + c0 + ch * 8, crs);
+  const float* const src[2] = {partial + c0, partial + qstride + c0};
+  double tot[2];
+  group_reduce<2>(src, P, rstride, tot);
+  if (threadIdx.x < FM_CG) {
+    const int c = c0 + threadIdx.x;
+    const float v1 = (float)(tot[0] / (double)count), v2 = (float)(tot[1] / (double)count);
+    s_k1[threadIdx.x] = v1;
+    s_k2[threadIdx.x] = v2;
+    if (blockIdx.y == 0) {
+      if (dgamma) dgamma[c] = (float)tot[1];
+      if (dbeta) dbeta[c] = (float)tot[0];
+      k1[c] = v1;
+      k2[c] = v2;
+    }
+  }
+  __syncthreads();
+  float ck1[8], ck2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ck1[j] = s_k1[ch * 8 + j]; ck2[j] = s_k2[ch * 8 + j]; }
+  for (int r = m_lo + r0; r < m_hi; r += RPP) {
+    const size_t e = (size_t)r * C + c0 + ch * 8;
+    uint4 gv = gv0, yv = yv0, ov = make_uint4(0u, 0u, 0u, 0u), rv = ov;
+    if (r != m_lo + r0) { gv = ld16(gin + e); yv = ld16(y + e); }
+    if (acc_dy) ov = ld16(dy + e);
+    if (dres && acc_dres) rv = ld16(dres + e);
+    float g[8], v[8], o[8];
+    unpack_bf8(gv, g);
+    unpack_bf8(yv, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = ca[j] * (g[j] - ck1[j] - (v[j] - cmu[j]) * crs[j] * ck2[j]);
+    if (acc_dy) {
+      unpack_bf8(ov, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += v[j];
+    }
+    st16(dy + e, pack_bf8(o));
+    if (dres) {
+      if (acc_dres) {
+        unpack_bf8(rv, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += v[j];
+      }
+      st16(dres + e, pack_bf8(g));
+    }
+  }
+}
+
 // ---- stem: out = act(maxpool3x3s2(y * scale + shift)), argmax (0..8, first maximum in row-major window order) ----
 __global__ __launch_bounds__(EW_THREADS) void bn_pool_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, bf16_t* __restrict__ out,
@@ -1167,6 +1360,50 @@ extern "C" int yolo_bn_bwd_finalize_grouped(const float* partial, int P, int64_t
   }
   hipLaunchKernelGGL(bn_bwd_finalize_grouped_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,
                      (size_t)q_stride, C, which, count, g, k1, k2);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+namespace {
+// row slices of the merged small-map launches: ~256 workgroups in all, at least 256 rows each
+int fm_slices(int64_t M, int C) {
+  const int groups = C / FM_CG;
+  int ms = (256 + groups - 1) / groups;
+  const int64_t cap = (M + 255) / 256;
+  if (ms > cap) ms = (int)cap;
+  return ms < 1 ? 1 : ms;
+}
+}  // namespace
+
+extern "C" int yolo_bn_finalize_act_fwd(const float* psum, const float* psq, int P, int64_t row_stride, int C, float count, const float* gamma,
+                                        const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* scale,
+                                        float* shift, float* mean, float* rstd, const void* y, const void* res, void* out,
+                                        uint8_t* relu_mask, int64_t M, int relu, void* stream) {
+  YOLO_CHECK_ARG(psum && psq && gamma && beta && scale && shift && mean && rstd && y && out, "null pointer");
+  YOLO_CHECK_ARG(P > 0 && C > 0 && C % FM_CG == 0 && count > 0.f && M > 0 && M * (int64_t)C < (int64_t)1 << 31, "bad size (C must be a multiple of 32)");
+  YOLO_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "moving_mean and moving_var go together");
+  YOLO_CHECK_ARG(!relu_mask || relu, "relu_mask needs relu");
+  const int ms = fm_slices(M, C);
+  const int rows_per = (int)((M + ms - 1) / ms);
+  hipLaunchKernelGGL(bn_finalize_act_kernel, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, psum, psq, P, (size_t)row_stride, C, count,
+                     gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd, (const bf16_t*)y, (const bf16_t*)res,
+                     (bf16_t*)out, relu_mask, (int)M, rows_per, relu);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_bwd_finalize_apply(const float* partial, int P, int64_t row_stride, int64_t q_stride, int C, float count, float* dgamma,
+                                          float* dbeta, float* k1, float* k2, const void* g, const void* y, const float* a1,
+                                          const float* mean, const float* rstd, void* dy, int acc_dy, void* dres, int acc_dres, int64_t M,
+                                          void* stream) {
+  YOLO_CHECK_ARG(partial && k1 && k2 && g && y && a1 && mean && rstd && dy, "null pointer");
+  YOLO_CHECK_ARG(P > 0 && C > 0 && C % FM_CG == 0 && count > 0.f && M > 0 && M * (int64_t)C < (int64_t)1 << 31, "bad size (C must be a multiple of 32)");
+  YOLO_CHECK_ARG(q_stride >= C && row_stride >= 2 * q_stride, "bad strides");
+  const int ms = fm_slices(M, C);
+  const int rows_per = (int)((M + ms - 1) / ms);
+  hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,
+                     (size_t)q_stride, C, count, dgamma, dbeta, k1, k2, (const bf16_t*)g, (const bf16_t*)y, a1, mean, rstd, (bf16_t*)dy, acc_dy,
+                     (bf16_t*)dres, acc_dres, (int)M, rows_per);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

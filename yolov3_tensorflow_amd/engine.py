@@ -195,6 +195,10 @@ class Graph(object):
         # the stem's backward pass (un-pool + BatchNorm apply + weight gradient) as one kernel that never writes the pre-pool gradient
         # (PoolOp.plan_fusion; YOLO_STEM_BWD=0 for A/B runs)
         self.stem_bwd = os.environ.get('YOLO_STEM_BWD', '1') != '0'
+        # small maps: BatchNorm finalize + apply in one launch when a unit has at most this many partial rows (0 = never; forward and
+        # backward; ops.bn_finalize_act_fwd / ops.bn_bwd_finalize_apply)
+        self.fin_merge_rows = int(os.environ.get('YOLO_FIN_MERGE_ROWS', '128'))
+        self.fin_merge_bwd_rows = int(os.environ.get('YOLO_FIN_MERGE_BWD_ROWS', str(self.fin_merge_rows)))
         self.vals = []
         self.bns = []            # every keras BatchNormalization (for checkpoints)
         self.bn_groups = []      # allocation units: a BNState or a MultiBN
@@ -830,7 +834,24 @@ class ApplyOp(object):
             psum, psq, P, rs = flat, flat[self.C:], self.P, 2 * self.C
         bn.fwd_finalize(psum, psq, P, rs, self.M, self.g.training)
 
+    def _merged_fwd(self):
+        """(psum, psq, P, row_stride) if this unit's finalize + apply run as one launch: training, one plain BatchNorm over a conv output
+        with few partial rows, no BatchNorm on the other operand"""
+        g, mb, m = self.g, self.m_bn, self.m_src
+        if not (g.training and g.fin_merge_rows and mb is not None and self.o_bn is None and m.kind == 'conv' and isinstance(mb, BNState)
+                and len(mb.parts) == 1 and self.C % 32 == 0):
+            return None
+        st = m.stats
+        return st if st[2] <= g.fin_merge_rows else None
+
     def forward(self):
+        st = self._merged_fwd()
+        if st is not None:
+            mb = self.m_bn
+            ops.bn_finalize_act_fwd(st[0], st[1], st[2], st[3], self.C, self.M, mb.v_gamma, mb.v_beta, BN_EPSILON, self.g.bn_momentum,
+                                    mb.moving_mean, mb.moving_var, mb.scale, mb.shift, mb.mean, mb.rstd, self.m_src.buf, self.out.buf,
+                                    self.M, self.relu, res=None if self.o_src is None else self.o_src.buf, mask=self.mask)
+            return
         if self.m_bn is not None:
             self._finalize_bn(self.m_src, self.m_bn)
         if self.o_bn is not None:
@@ -915,6 +936,13 @@ class ApplyOp(object):
         if self.producer is not None:
             # out.grad already holds the masked gradient and self.fpartial its tile sums (left by the producer's epilogue)
             y1, b1, y2, b2 = self._reduce_operands()
+            if (b2 is None and b1 is mb and isinstance(mb, BNState) and len(mb.parts) == 1 and self.C % 32 == 0 and not self.skip_dy
+                    and 0 < self.frows <= self.g.fin_merge_bwd_rows):
+                dres = o.grad if (o is not None and not self.skip_dres) else None          # (ob is None here: b2 is None and b1 is mb)
+                ops.bn_bwd_finalize_apply(self.fpartial.view(-1), self.frows, self.C, self.M, mb.v_dgamma, mb.v_dbeta, mb.k1, mb.k2, out.grad,
+                                          m.buf, mb.scale, mb.mean, mb.rstd, self.M, m.dy if self.m_dst == 'dy' else m.grad,
+                                          acc_dy=self.m_acc, dres=dres, acc_dres=self.o_acc)
+                return
             b1.bwd_finalize(self.fpartial.view(-1), self.frows, self.C, 1, self.M)
             if b2 is not None:
                 b2.bwd_finalize(self.fpartial.view(-1), self.frows, self.C, 2, self.M)

@@ -165,6 +165,24 @@ def bn_finalize(psum, psq, P, row_stride, Cc, count, gamma, beta, eps, momentum,
           'yolo_bn_finalize')
 
 
+def bn_finalize_act_fwd(psum, psq, P, row_stride, Cc, count, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd,
+                        y, out, M, relu, res=None, mask=None):
+    """bn_finalize + bn_act_fwd in one launch (small maps: few partial rows, C % 32 == 0)"""
+    check(_lib.load().yolo_bn_finalize_act_fwd(_p(psum), _p(psq), P, row_stride, Cc, float(count), _p(gamma), _p(beta), eps, momentum,
+                                               _p(moving_mean), _p(moving_var), _p(scale), _p(shift), _p(mean), _p(rstd), _p(y), _p(res),
+                                               _p(out), _p(mask), M, int(bool(relu)), _stream()), 'yolo_bn_finalize_act_fwd')
+
+
+def bn_bwd_finalize_apply(partial, P, Cc, count, dgamma, dbeta, k1, k2, g, y, a1, mean, rstd, M, dy, acc_dy=False, dres=None, acc_dres=False,
+                          row_stride=None, q_stride=None):
+    """bn_bwd_finalize (which = 1) + bn_act_bwd_apply (masked gradient g, relu = 0) in one launch"""
+    q = Cc if q_stride is None else q_stride
+    rs = 3 * q if row_stride is None else row_stride
+    check(_lib.load().yolo_bn_bwd_finalize_apply(_p(partial), P, rs, q, Cc, float(count), _p(dgamma), _p(dbeta), _p(k1), _p(k2), _p(g), _p(y),
+                                                 _p(a1), _p(mean), _p(rstd), _p(dy), int(bool(acc_dy)), _p(dres), int(bool(acc_dres)), M,
+                                                 _stream()), 'yolo_bn_bwd_finalize_apply')
+
+
 def _ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
