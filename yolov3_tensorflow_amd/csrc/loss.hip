@@ -22,6 +22,7 @@ struct LossCfg {
   yolo_loss_config c;
   int P[3];       // predictions per image per head = H*W*B
   float area[3];  // H*W as float
+  int nb[3];      // workgroups of loss_main_kernel per image and head (its grid.x is their sum)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -121,10 +122,13 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
                                                                const int* __restrict__ assign, const int* __restrict__ current_num,
                                                                float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2,
                                                                bf16_t* __restrict__ e0, bf16_t* __restrict__ e1, bf16_t* __restrict__ e2,
-                                                               float* __restrict__ partial /*[N][3][gridDim.x][6]*/, float inv_n) {
+                                                               float* __restrict__ partial /*[N][3][nbx][6]*/, int nbx, float inv_n) {
   extern __shared__ float sh[];
   const yolo_loss_config& c = cfg.c;
-  const int h = blockIdx.y, n = blockIdx.z, T = c.T, L = c.L;
+  // grid.x runs over the workgroups of head 0, then 1, then 2 (a (max, 3, N) grid left 55 % of the workgroups without cells at 416^2)
+  const int h = (int)blockIdx.x < cfg.nb[0] ? 0 : ((int)blockIdx.x < cfg.nb[0] + cfg.nb[1] ? 1 : 2);
+  const int bx = (int)blockIdx.x - (h == 0 ? 0 : (h == 1 ? cfg.nb[0] : cfg.nb[0] + cfg.nb[1]));
+  const int n = blockIdx.y, T = c.T, L = c.L;
   const int H = c.H[h], W = c.W[h], B = c.B[h], ldc = c.ldc[h], HW = H * W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // LDS: GT table [T][8] (x0,y0,x1,y1,area,valid,-,-), assignment [T], GT class [T], channel table [ldc] (u16),
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
 
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // xy, wh, noobj, obj, class, rectified (un-normalised sums)
   const int cpw = 64 / B;                            // whole cells per wave
-  const int cell_base = (blockIdx.x * (LM_THREADS / 64) + wave) * cpw;
+  const int cell_base = (bx * (LM_THREADS / 64) + wave) * cpw;
   if (cell_base < HW) {  // wave-uniform
     const int cl = lane / B, b = lane - cl * B;
     const int cell = cell_base + cl;
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
     const int pid = cell * B + b;
     float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float mx = 0.f, se = 1.f, nvalid = -1.f;
+    bool resp = false;
     if (pv) {
       const int row = cell / W, col = cell - row * W;
       const float* t = lg + (size_t)cell * ldc + b * L;
@@ -239,12 +244,26 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
       }
 #pragma unroll
       for (int j = 0; j < 5; ++j) g[j] *= inv_n;
-      // class term of a responsible prediction (:361-364): softmax statistics + loss here, gradient in the store pass
-      if (nresp > 0 && C > 0) {
-        mx = -INFINITY;
-        for (int k = 0; k < C; ++k) mx = fmaxf(mx, t[5 + k]);
-        se = 0.f;
-        for (int k = 0; k < C; ++k) se += expf(t[5 + k] - mx);
+      resp = nresp > 0 && C > 0;
+    }
+    // class term of a responsible prediction (:361-364): softmax statistics + loss here, gradient in the store pass.  Responsible lanes
+    // are rare (<= T per image and head) and each needs max / sum over its C class logits: the WAVE reads them, 64 classes at a time
+    // (a lane walking its own 80 logits twice kept its whole wave waiting for 160 dependent loads: 18 of the kernel's 64 us)
+    for (unsigned long long todo = __ballot(resp); todo; todo &= todo - 1) {
+      const int src = __ffsll((long long)todo) - 1;
+      const int scl = src / B;
+      const float* tc = lg + (size_t)(cell_base + scl) * ldc + (src - scl * B) * L + 5;
+      float m_ = -INFINITY;
+      for (int k = lane; k < C; k += 64) m_ = fmaxf(m_, tc[k]);
+      m_ = wave_max(m_);
+      float s_ = 0.f;
+      for (int k = lane; k < C; k += 64) s_ += expf(tc[k] - m_);
+      s_ = wave_sum(s_);
+      if (lane == src) { mx = m_; se = s_; }
+    }
+    if (pv) {
+      const float* t = lg + (size_t)cell * ldc + b * L;
+      if (resp) {
         int nv = 0;
         for (int k = 0; k < T; ++k) {
           if (s_as[k] != pid) continue;
@@ -267,20 +286,32 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
     const int ncell = min(cpw, HW - cell_base);
     const int q = ldc >> 2;  // lanes per row (ldc = 64 * 2^k)
     const float gscale = w_cls * inv_n;
+    // ldc == 256 (the 80-class heads): a lane keeps its 4 channels for every row -- table entries read once, and a lane none of whose
+    // channels is a box / confidence logit has nothing to read from LDS in a row without a responsible anchor (nearly all rows)
+    const bool keep = q == 64;
+    unsigned e_keep[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+    bool small = true;
+    if (keep) {
+      small = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { e_keep[u] = s_lut[lane * 4 + u]; small = small || (e_keep[u] != 0xFFFFu && (e_keep[u] & 0xFF) < 5); }
+    }
     for (int idx = lane; idx < ncell * q; idx += 64) {
-      const int clx = idx / q, c4 = idx - clx * q;
-      float v[4];
+      const int clx = keep ? (idx >> 6) : idx / q, c4 = keep ? lane : idx - clx * q;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      bool any = false;                                        // does any anchor of this cell carry a class gradient?  (broadcast reads)
+      for (int bb = 0; bb < B; ++bb) any = any || s_w[(clx * B + bb) * 8 + 7] >= 0.f;
+      if (any || small)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ch = c4 * 4 + u;
-        const unsigned e = s_lut[ch];
-        v[u] = 0.f;
+        const unsigned e = keep ? e_keep[u] : (unsigned)s_lut[ch];
         if (e != 0xFFFFu) {
           const int bb = e >> 8, j = e & 0xFF;
           const int pl = clx * B + bb;
           if (j < 5) {
             v[u] = s_w[pl * 8 + j];
-          } else if (s_w[pl * 8 + 7] >= 0.f) {               // class logit of a responsible prediction: w*(n*softmax - counts)/N
+          } else if (any && s_w[pl * 8 + 7] >= 0.f) {        // class logit of a responsible prediction: w*(n*softmax - counts)/N
             const int k = ch - bb * L - 5;
             const int rpid = (cell_base + clx) * B + bb;
             const float sm = expf(lg[(size_t)(cell_base + clx) * ldc + ch] - s_w[pl * 8 + 5]) / s_w[pl * 8 + 6];
@@ -311,34 +342,62 @@ __global__ __launch_bounds__(LM_THREADS) void loss_main_kernel(LossCfg cfg, cons
   __syncthreads();
   if (threadIdx.x < 6) {
     const float s = s_red[threadIdx.x] + s_red[6 + threadIdx.x] + s_red[12 + threadIdx.x] + s_red[18 + threadIdx.x];
-    partial[(((size_t)n * 3 + h) * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = s;
+    partial[(((size_t)n * 3 + h) * nbx + bx) * 6 + threadIdx.x] = s;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- 3. finalize
-// 9 waves, two outputs each: output o = term k = o / 3 of head h = o % 3, reduced over all images and blocks
-__global__ __launch_bounds__(9 * 64) void loss_finalize_kernel(LossCfg cfg, const float* __restrict__ partial, int N, int nbx, float inv_n,
-                                                               int batch_global, int* __restrict__ current_num, float* __restrict__ terms /*[6][3]*/,
-                                                               float* __restrict__ total) {
+// output o = term k = o / 3 of head h = o % 3, reduced over all images and blocks
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(LossCfg cfg, const float* __restrict__ partial, int N, int nbx, float inv_n,
+                                                            int batch_global, int* __restrict__ current_num, float* __restrict__ terms /*[6][3]*/,
+                                                            float* __restrict__ total) {
+  __shared__ float s_w[16][18];
   __shared__ float s_t[18];
   const yolo_loss_config& c = cfg.c;
   const bool rect = c.rectified_coord_num >= 0 && current_num[0] <= c.rectified_coord_num;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int o = wave; o < 18; o += 9) {
-    const int k = o / 3, h = o - k * 3;
+  // This launch is latency, not work: a thread takes whole rows (image, head, block) of 6 terms, so that every load of the launch is in
+  // flight after one or two trips (18 waves walking one output each needed ~8 dependent round trips: 11.9 us).  Rows of head h beyond
+  // its own nb[h] workgroups are never written and never read.
+  const int r0 = N * cfg.nb[0], r1 = r0 + N * cfg.nb[1], r2 = r1 + N * cfg.nb[2];
+  float acc[3][6];
+#pragma unroll
+  for (int h = 0; h < 3; ++h)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[h][k] = 0.f;
+  for (int r = threadIdx.x; r < r2; r += 1024) {
+    const int h = r < r0 ? 0 : (r < r1 ? 1 : 2);
+    const int i = r - (h == 0 ? 0 : (h == 1 ? r0 : r1));
+    const int nbh = cfg.nb[h];
+    const int n = i / nbh, b = i - n * nbh;
+    const float2* src = reinterpret_cast<const float2*>(partial + (((size_t)n * 3 + h) * nbx + b) * 6);
+    const float2 a = src[0], b2 = src[1], d = src[2];
+    const float v[6] = {a.x, a.y, b2.x, b2.y, d.x, d.y};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {           // (static indexing: the accumulators stay in registers)
+      if (h == 0) acc[0][k] += v[k];
+      else if (h == 1) acc[1][k] += v[k];
+      else acc[2][k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 3; ++h)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float s = wave_sum(acc[h][k]);
+      if (lane == 0) s_w[wave][k * 3 + h] = s;
+    }
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    const int o = threadIdx.x, k = o / 3, h = o - k * 3;
     float s = 0.f;
-    for (int i = lane; i < N * nbx; i += 64) {
-      const int n = i / nbx, b = i - n * nbx;
-      s += partial[(((size_t)n * 3 + h) * nbx + b) * 6 + k];
-    }
-    s = wave_sum(s);
-    if (lane == 0) {
-      const float wt = (k == 0 ? c.w_xy[h] : k == 1 ? c.w_wh[h] : k == 2 ? c.w_noobj[h] : k == 3 ? c.w_obj[h] : k == 4 ? c.w_cls[h] : c.w_rect[h]);
-      float v = wt * s * inv_n;
-      if (k == 5 && !rect) v = 0.f;
-      s_t[o] = v;
-      terms[o] = v;
-    }
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += s_w[w][o];
+    const float wt = (k == 0 ? c.w_xy[h] : k == 1 ? c.w_wh[h] : k == 2 ? c.w_noobj[h] : k == 3 ? c.w_obj[h] : k == 4 ? c.w_cls[h] : c.w_rect[h]);
+    float v = wt * s * inv_n;
+    if (k == 5 && !rect) v = 0.f;
+    s_t[o] = v;
+    terms[o] = v;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -428,6 +487,10 @@ extern "C" int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_glo
     max_ldc = max_ldc > c->ldc[h] ? max_ldc : c->ldc[h];
   }
   const int nbx = loss_nbx(c);
+  for (int h = 0; h < 3; ++h) {
+    const int cells_per_block = (LM_THREADS / 64) * (64 / c->B[h]);
+    cfg.nb[h] = (c->H[h] * c->W[h] + cells_per_block - 1) / cells_per_block;
+  }
   int* assign = assign_out ? assign_out : reinterpret_cast<int*>(workspace);
   float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (size_t)N * c->T * 3 * 4);
   hipStream_t st = (hipStream_t)stream;
@@ -437,11 +500,11 @@ extern "C" int yolo_loss_fwd_bwd(const yolo_loss_config* c, int N, int batch_glo
   YOLO_LAUNCH_CHECK();
   const size_t lds = (size_t)lm_lds_floats(c->T, max_ldc) * 4;
   YOLO_CHECK_ARG(lds <= 64 * 1024, "T / ldc too large for the loss kernel's LDS budget");
-  hipLaunchKernelGGL(loss_main_kernel, dim3(nbx, 3, N), dim3(LM_THREADS), lds, st, cfg, logits8, logits16, logits32, labels, assign,
-                     current_num, dlogits8, dlogits16, dlogits32, (bf16_t*)dlogits8_bf16, (bf16_t*)dlogits16_bf16, (bf16_t*)dlogits32_bf16,
-                     partial, inv_n);
+  hipLaunchKernelGGL(loss_main_kernel, dim3(cfg.nb[0] + cfg.nb[1] + cfg.nb[2], N), dim3(LM_THREADS), lds, st, cfg, logits8, logits16, logits32,
+                     labels, assign, current_num, dlogits8, dlogits16, dlogits32, (bf16_t*)dlogits8_bf16, (bf16_t*)dlogits16_bf16,
+                     (bf16_t*)dlogits32_bf16, partial, nbx, inv_n);
   YOLO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(9 * 64), 0, st, cfg, partial, N, nbx, inv_n, batch_global, current_num, terms, total);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, cfg, partial, N, nbx, inv_n, batch_global, current_num, terms, total);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
