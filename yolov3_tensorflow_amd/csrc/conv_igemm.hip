@@ -523,7 +523,7 @@ template <int BM, int BN, int NW, int WS, bool BNEPI>
 __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, const float* __restrict__ bias, void* __restrict__ Yv, int ldy,
                                                             int accumulate, float* __restrict__ stat_sum, float* __restrict__ stat_sq,
                                                             int Kout, int tiles_n, BnEpi bnepi) {
-  constexpr int WN = (BN == 128) ? 2 : 1;
+  constexpr int WN = (BN == 128 || (BM == 64 && BN == 64)) ? 2 : 1;   // (64 x 64: 2 x 2 waves of 32 x 32 -- 4 fragment reads per 4 MFMAs instead of 5)
   constexpr int WM = NW / WN;
   constexpr int PT = BM / WM / 16;
   constexpr int CT = BN / WN / 16;
