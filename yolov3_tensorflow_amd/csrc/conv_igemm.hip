@@ -1472,6 +1472,7 @@ int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int l
 
 extern int g_fused_min_chunks;
 extern int g_pool_scatter;
+extern int g_reduce_cap;        // eltwise.hip
 extern int g_fused_small_chunks;   // eltwise.hip
 
 extern "C" int yolo_set_tuning(const char* name, int value) {
@@ -1484,6 +1485,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "s2_classes")) { YOLO_CHECK_ARG(value == 0 || value == 1, "s2_classes"); g_s2_classes = value; }
   else if (!strcmp(name, "wgrad_target")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "wgrad_target"); g_wgrad_target = value; }
   else if (!strcmp(name, "bn_fused_small_grid")) { YOLO_CHECK_ARG(value == 0 || (value >= 16 && value <= 255), "bn_fused_small_grid"); g_fused_small_chunks = value; }
+  else if (!strcmp(name, "reduce_cap")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "reduce_cap"); g_reduce_cap = value; }
   else if (!strcmp(name, "pool_scatter")) { YOLO_CHECK_ARG(value == 0 || value == 1, "pool_scatter"); g_pool_scatter = value; }
   else if (!strcmp(name, "wgrad_pipe")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_pipe"); g_wgrad_pipe = value; }
   else if (!strcmp(name, "wgrad_ring")) { YOLO_CHECK_ARG(value == 2 || value == 3, "wgrad_ring"); g_wgrad_ring = value; }

@@ -1269,10 +1269,13 @@ inline bool chan_ok(int C) {  // C/8 must divide 256
   int cv = C / 8;
   return cv <= 256 && (256 % cv) == 0;
 }
+}  // namespace
+int g_reduce_cap = 512;     // "reduce_cap" tuning: workgroups (= partial rows) of the column-statistics passes; set before buffers are sized
+namespace {
 inline int reduce_grid(int M, int C) {
   const int RL = EW_THREADS / (C / 8);
   int b = (M + RL - 1) / RL;
-  if (b > 512) b = 512;   // 2 workgroups per CU; the finalize kernels then reduce <= 512 partial rows
+  if (b > g_reduce_cap) b = g_reduce_cap;   // 512 = 2 workgroups per CU; the finalize kernels then reduce <= 512 partial rows
   if (b < 1) b = 1;
   return b;
 }
