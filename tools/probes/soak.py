@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import bench
 dev = torch.device('cuda:0')
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2500
+if len(sys.argv) > 2:                       # K.epsilon (reference run.py:26 sets 1e-8, whose 1 - eps is 1.0f: no upper clip); 1e-7 makes the clip real
+    from yolov3_tensorflow_amd import backend
+    backend.set_epsilon(float(sys.argv[2]))
 model, loss, opt, grids = bench.build_model('resnet-18', 416, 416, 32, 80, dev)
 images, labels = bench.synthetic_batch(32, 416, 416, 80, 0)
 model.stage_batch(images, labels)
