@@ -76,11 +76,18 @@ typedef struct {
  * writes per-channel partial sums / sums of squares of the bf16-rounded outputs: arrays [stat_rows][Cout] where
  * stat_rows = yolo_conv2d_stat_rows(p) (reduced later by yolo_bn_finalize). */
 int yolo_conv2d_stat_rows(const yolo_conv_problem* p);
+/* Which kernel yolo_conv2d_fwd would launch for p under the current tuning, without launching (tests, tools): info[0] = family (0 implicit
+ * GEMM, 1 LDS-resident strip, 2 big-tile strip = conv_pstrip.hip, 3 RGB stem), info[1] / info[2] = pixel / channel tile, info[3] = pixels a
+ * tile owns (big-tile: <= info[1]), info[4] = workgroups, info[5] = dynamic LDS bytes (big-tile), info[6] = weight-ring stages (big-tile),
+ * info[7] = reserved.  The data gradient of p is planned like the forward pass of the problem with Cin and Cout swapped. */
+int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info8);
 /* Test / benchmark hook: override a kernel-selection heuristic.  "strip_bm": -1 auto (default), 0 never use the LDS-resident strip
  * kernel for 3x3 stride-1 convolutions, 64 / 128 / 256 force its pixel tile; "strip_bn": 0 auto, 64 / 128; "wgrad_strip": 0 / 1;
  * "stem_direct": 1 (default) / 0 the RGB stem (Cin 8, Cout 64, 3x3 stride 2) on its row-walking kernel or on the implicit GEMM (changes yolo_conv2d_stat_rows);
  * "dw_tiled": 1 (default) / 0 the mixed depthwise forward / data gradient on its tiled kernel or on the row-tile kernel, > 1 = workgroups per
  * 64-channel slab of the tiled kernel's persistent grid (default 512);
+ * "pstrip": -1 auto (default) / 0 never / 1 + v force variant v (0: 352 pixels x 64 channels, 1: 176 x 128) of the one-tile-per-CU
+ * kernel for 3x3 stride-1 convolutions (conv_pstrip.hip; changes yolo_conv2d_stat_rows);
  * "strip_ws": 0 auto / 2 / 3 weight-ring stages; "s2_classes": 0 / 1 stride-2 data gradient as four dense parity classes;
  * "wgrad_target": workgroups the split-K plan aims at (64..4096, default 384; changes yolo_conv2d_wgrad_workspace_bytes);
  * "wgrad_xcd": 0 / 1 XCD-chunked 1-D weight-gradient grids; "wgrad_ring": 2 / 3 operand stages and "wgrad_pipe": 0 / 1 software-pipelined

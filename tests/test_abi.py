@@ -74,7 +74,16 @@ def test_kernel_plans_are_consistent_without_gpu():
     p = ops.conv_problem(N, H, W, 128, 128, 3, 1, 'same')
     M = N * H * W
     try:
+        # the one-tile-per-CU kernel takes this layer: 512 tiles of 338 pixels (6.5 image rows) x 64 channels, two rounds on 256 CUs
+        ops.set_tuning('pstrip', -1)
+        plan = ops.conv2d_fwd_plan(p)
+        assert plan['family'] == 'pstrip' and plan['tile_pixels'] == 338 and plan['workgroups'] == 512 and plan['lds_bytes'] <= 160 * 1024
+        assert ops.conv2d_stat_rows(p) == M // 338
+        ops.set_tuning('pstrip', 2)                         # forced 176 x 128 variant: 169 pixels per tile
+        assert ops.conv2d_fwd_plan(p)['tile_pixels'] == 169 and ops.conv2d_stat_rows(p) == M // 169
+        ops.set_tuning('pstrip', 0)
         ops.set_tuning('strip_bm', 0)                      # implicit-GEMM kernel: 128-pixel tiles for this shape
+        assert ops.conv2d_fwd_plan(p)['family'] == 'igemm'
         assert ops.conv2d_stat_rows(p) == (M + 127) // 128
         for bm in (64, 128, 256):
             ops.set_tuning('strip_bm', bm)
@@ -85,6 +94,7 @@ def test_kernel_plans_are_consistent_without_gpu():
         assert ops.conv2d_stat_rows(p1) == (M + 127) // 128  # 1x1: never the strip kernel
     finally:
         ops.set_tuning('strip_bm', -1)
+        ops.set_tuning('pstrip', 0)
     ws = ops.conv2d_wgrad_workspace_bytes(p)
     assert ws % (128 * 9 * 128 * 4) == 0 and 2 <= ws // (128 * 9 * 128 * 4) <= 384     # whole slabs, one round of workgroups
     mp = ops.mix_problem(N, 104, 104, 64, [0, 32, 48, 56, 64], [3, 5, 7, 9])

@@ -57,6 +57,7 @@ SIGNATURES = {
     'yolo_seq_run': (I, [I, I, I]),
     'yolo_seq_free': (I, [I]),
     'yolo_conv2d_stat_rows': (I, [CP]),
+    'yolo_conv2d_fwd_plan': (I, [CP, P]),
     'yolo_set_tuning': (I, [C.c_char_p, I]),
     'yolo_conv2d_fwd': (I, [CP, P, P, P, P, P, I, P, P, P]),
     'yolo_conv2d_dgrad': (I, [CP, P, P, P, I, P]),

@@ -6,333 +6,22 @@
 // kernel tap of the source tensor; the (optional) nearest 2x upsample + channel concat of the FPN necks
 // (yolov3_detector.py:115-116,140-141) is resolved inside the gather, so the concatenated tensor never exists.
 //
-// fwd/dgrad kernel : 128 pixels x {128|64} channels per 256-thread workgroup (4 wave64), BK = 64, register-staged
-//                    global->LDS with an XOR-swizzled image (conflict-free ds_read_b128), double-buffered LDS,
-//                    v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the A operand so that every lane ends up holding
-//                    4 consecutive output channels of one pixel (8-byte bf16 / 16-byte f32 NHWC stores).
-//                    Epilogue options: bias, f32 output, accumulate (dgrad fan-in), BatchNorm partial statistics.
-// wgrad kernel     : dW[co][kcol] += sum_pixels dY[pix][co] * X[pix][kcol]; both operands are pixel-major in memory,
-//                    so fragments are read with ds_read_b64_tr_b16 (hardware transpose); split over pixel ranges,
-//                    fp32 atomics into dW.
-#include "common.h"
-#include <type_traits>
-#include <string.h>
+// igemm_fwd_kernel     : {128,64} pixels x {128,64} channels per workgroup (8 waves on 128 x 128, else 4), BK = 64; both operands arrive by
+//                        LDS-DMA (global_load_lds_dwordx4 / buffer_load ... lds) into a 2-stage ring with the XOR swizzle applied on the
+//                        SOURCE address (the DMA writes lane-linear), one raw s_barrier + counted s_waitcnt per K-step,
+//                        v_mfma_f32_16x16x32 with the WEIGHT tile as the A operand so that a lane holds 4 consecutive channels of a pixel.
+//                        Stride-2 data gradients run as four dense parity classes in one launch.
+// conv3x3_strip_kernel : 3x3 / stride-1 layers: the pixel strip of a tile is loaded once per 64-channel slice, the nine taps are nine
+//                        shifted reads of that LDS image; only the weight tile streams through a ring.
+// epilogue (shared, conv_common.h): bf16 tile transposed through LDS -> whole NHWC row stores (also the fan-in accumulate path),
+//                        BatchNorm partial statistics (one row per pixel tile), or the BatchNorm-backward reduce of a data gradient;
+//                        float32 logits + bias are written directly.
+// wgrad kernels        : dW[co][kcol] = sum_pixels dY[pix][co] * X[pix][kcol]; both operands are pixel-major in memory, so fragments are
+//                        read with ds_read_b64_tr_b16 (hardware transpose); split over pixel ranges into per-layer SLABS (plain stores,
+//                        no atomics) that one launch per gradient bucket sums (wgrad_reduce_batched_kernel).
+#include "conv_common.h"
 
 namespace {
-
-struct Gather {
-  const bf16_t* src0;  // half-resolution source of the first C0 channels (nullptr if C0 == 0)
-  const bf16_t* src1;  // full-resolution source of the remaining C1 channels
-  int Hs, Ws;          // spatial size of the (virtual, concatenated) source
-  int C0, C1;
-  int lgC8;            // log2((C0 + C1) / 8)
-  int Ho, Wo;          // row space
-  int S, RS;           // kernel width, taps
-  int smul, pad_h, pad_w, den;  // src coord = (row * smul - pad + tap) / den  (valid iff divisible and in range)
-  int M;               // rows (< 2^24: row decode uses float reciprocals)
-  int Kg;              // GEMM K = RS * (C0 + C1)
-  float rhw, rw;       // 1 / (Ho * Wo), 1 / Wo
-  int magicS;          // tap / S == (tap * magicS) >> 16 for tap < 128
-  // ---- stride-2 data gradient as 4 parity classes (blockIdx.y = 2 * (h & 1) + (w & 1) of the output pixel): each class is a dense
-  // stride-1 correlation over dY with 1 or 2 of the 3 taps per dimension, written to every other row / column of dX; the kernel
-  // specialises its copy of this struct per class (s2 == 0: everything below is unused)
-  int s2;
-  int s2_ny;           // classes launched (grid y): 4, or 1 = only the even / even class (1x1 stride-2: the other positions get nothing)
-  int N, S_full;       // images; tap columns of the (flipped) weight tensor
-  int wKg;             // weight row stride in elements (9 * C)
-  struct Dim { int n, pad, size, t0, t1; } rowd[2], cold[2];   // per parity: taps, padding, class grid size, flipped tap indices
-  int OH, OW;          // dX spatial size
-};
-
-// per-launch view of the class a workgroup works on
-struct ClassView { int on, wbase, wdr, wds, two, Hc, Wc, OH, OW, ph, pw; float rhw, rw; };
-
-// BatchNorm-backward reduce fused into the data-gradient epilogue: the tile being written IS dL/d(out) of a BN(+ReLU)(+residual) unit, so
-// the epilogue masks it with the unit's ReLU sign bits (mask: one byte per 8-channel chunk, or null), stores the masked gradient g and
-// leaves the per-channel partial sums  sum g,  sum g xhat  (and  sum g xhat2  of a shortcut BN) of its tile in partial[row][3][ld] --
-// the separate reduce pass over dout / out / y (and the grid barrier of the single-launch form) disappears.  partial == null: off.
-struct BnEpi {
-  const uint8_t* mask;
-  const bf16_t* y;  const float* mean;  const float* rstd;
-  const bf16_t* y2; const float* mean2; const float* rstd2;
-  float* partial;
-  const bf16_t* addend;   // fan-in source of an accumulating data gradient when it is not the output buffer itself (any instantiation)
-};
-struct Epi { float* ssum; float* ssq; BnEpi bn; };
-
-struct RowInfo { int n, hb, wb; };
-
-// full-rate 24-bit multiply-add (operands < 2^24; the 32-bit v_mul_lo_u32 is quarter rate)
-__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
-
-// q = m / d, r = m % d with a float reciprocal + one correction step (exact for m < 2^24): ~8 instructions instead of the ~40 of an
-// integer division -- the tile prologue decodes 4 rows per lane and was dominated by divisions
-__device__ __forceinline__ void fast_divmod(int m, int d, float rd, int& q, int& r) {
-  q = (int)((float)m * rd);
-  r = m - q * d;
-  if (r < 0) { --q; r += d; }
-  if (r >= d) { ++q; r -= d; }
-}
-
-__device__ __forceinline__ RowInfo decode_row(const Gather& g, int m) {
-  RowInfo r;
-  if (m >= g.M) { r.n = 0; r.hb = -(1 << 28); r.wb = -(1 << 28); return r; }
-  int rem, ho, wo;
-  fast_divmod(m, g.Ho * g.Wo, g.rhw, r.n, rem);
-  fast_divmod(rem, g.Wo, g.rw, ho, wo);
-  r.hb = ho * g.smul - g.pad_h;
-  r.wb = wo * g.smul - g.pad_w;
-  return r;
-}
-
-// XOR-swizzled [rows][64 bf16] image: 128-byte rows, 16-byte chunk index ^= row & 7.
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-
-// 16 bytes of zeros in global memory: the source of every out-of-image / out-of-K chunk of the LDS-DMA gathers
-__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// LDS-DMA of 16 bytes per lane through a raw buffer descriptor over [base, base + bytes): lanes whose byte offset is out of range
-// (e.g. 0x80000000) write zeros -- probed on gfx950 (tools/probes/buffer_lds_probe.hip).  The descriptor is wave-uniform (4 SGPRs).
-__device__ __forceinline__ void buffer_load_lds16(const void* base, unsigned bytes, void* lds, unsigned voffset) {
-  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)lds, 16, voffset, 0, 0, 0);
-}
-
-// address of one 16-byte k-chunk of one row, or the zero chunk
-__device__ __forceinline__ const bf16_t* gather_addr(const Gather& g, const RowInfo& r, int tap_r, int tap_s, int c, bool kvalid) {
-  int hn = r.hb + tap_r, wn = r.wb + tap_s;
-  bool ok = kvalid & (hn >= 0) & (wn >= 0);
-  if (g.den == 2) { ok = ok & (((hn | wn) & 1) == 0); hn >>= 1; wn >>= 1; }
-  ok = ok & (hn < g.Hs) & (wn < g.Ws);
-  const bf16_t* p = reinterpret_cast<const bf16_t*>(&g_zero16);
-  if (ok) {
-    if (c < g.C0) p = g.src0 + ((size_t)(r.n * (g.Hs >> 1) + (hn >> 1)) * (g.Ws >> 1) + (wn >> 1)) * g.C0 + c;
-    else          p = g.src1 + ((size_t)(r.n * g.Hs + hn) * g.Ws + wn) * g.C1 + (c - g.C0);
-  }
-  return p;
-}
-
-// XCD-aware tile order (MI355X deals consecutive workgroups round-robin over its 8 XCDs, each with a private L2): give every XCD a
-// contiguous run of tiles so that the tiles sharing a pixel panel / weight panel hit the same L2.  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
-// Weight-gradient grids: logical (x = k tile, y = co tile, z = pixel split).  Every workgroup of one split reads the same pixels of X and
-// dY, so with xcd != 0 the grid is launched 1-D and each XCD gets a contiguous run of logical ids (x fastest, then y, then z): the
-// tiles of a split land on one XCD close in time and share its L2 instead of fetching the range once per XCD (PMC: the 64-channel
-// 104 x 104 weight gradient fetched 259 MB for 88 MB of operands -- one read per kernel row).
-struct Bid3 { int x, y, z; };
-__device__ __forceinline__ Bid3 wgrad_block(int gx, int gy, int xcd) {
-  if (!xcd) return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
-  const int l = xcd_remap(blockIdx.x, gridDim.x);
-  const int x = l % gx, t = l / gx;
-  return {x, t % gy, t / gy};
-}
-
-constexpr int BK = 64;  // K elements per stage
-
-// Tile epilogue shared by the conv kernels: lane holds channels co..co+3 (rows of D) of pixel (column of D); acc[a][b] = channel tile a x
-// pixel tile b of this wave (wave grid WM pixels x WN channels).  bf16 outputs are staged through LDS (the operand buffers are free by
-// then), optional BatchNorm partial statistics go to one row per pixel tile.
-template <int BM, int BN, int NW, int WM, int WN, int PT, int CT, bool OUT_F32, bool BNEPI = false>
-__device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem, int M, int m0, int n0, int tile_m, const float* __restrict__ bias,
-                                              void* __restrict__ Yv, int ldy, int accumulate, float* __restrict__ stat_sum,
-                                              float* __restrict__ stat_sq, int Kout, int tid, int lane, int wm, int wn, const ClassView& cv,
-                                              const BnEpi& bn, int prow) {
-  const int cq = (lane >> 4) * 4;
-  float ssum[CT][4], ssq[CT][4];
-#pragma unroll
-  for (int a = 0; a < CT; ++a)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
-
-  if constexpr (OUT_F32) {   // float32 logits (+ bias): 16 bytes per lane, written straight from the accumulators
-#pragma unroll
-    for (int b = 0; b < PT; ++b) {
-      const int m = m0 + wm * (PT * 16) + b * 16 + (lane & 15);
-      if (m < M) {
-#pragma unroll
-        for (int a = 0; a < CT; ++a) {
-          const int co = n0 + wn * (CT * 16) + a * 16 + cq;
-          float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-          if (bias) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += bias[co + j];
-          }
-          float* y = reinterpret_cast<float*>(Yv) + (size_t)m * ldy + co;
-          if (accumulate) { float4 o = *reinterpret_cast<float4*>(y); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-          *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-    }
-  } else {
-    // bf16 activations: the tile is transposed through LDS (free now) so that every store instruction writes whole 128/256-byte
-    // NHWC rows -- straight from the accumulators each instruction wrote 16 scattered 32-byte segments, which cost more than the
-    // MFMAs of the whole tile on the 64-channel layers (ablation: 39 of 70 us)
-    constexpr int OLD = BN * 2 + 16;                  // LDS row stride in bytes (16-byte pad: conflict-free 8-byte writes)
-    // fused BatchNorm reduce: geometry of the write loop (a thread keeps its channel chunk and walks rows) and the global reads of its
-    // first NB rows (y, the fan-in addend, the sign byte), requested NOW so that they fly under the staging of the tile
-    constexpr int E_CPR = BN / 8, E_RG = NW * 64 / E_CPR, E_ITER = BM / E_RG, E_NB = E_ITER < 4 ? E_ITER : 4;
-    const int e_ch = tid % E_CPR, e_rg = tid / E_CPR, e_c = n0 + e_ch * 8;
-    uint4 e_yv[E_NB], e_ev[E_NB];
-    unsigned e_mk[E_NB], e_off[E_NB];
-    auto e_load = [&](int it0) {
-#pragma unroll
-      for (int k = 0; k < E_NB; ++k) {
-        const int row = e_rg + (it0 + k) * E_RG, m = m0 + row;
-        e_off[k] = 0xffffffffu;                        // element offsets (the host refuses tensors of 2^31 elements or more)
-        if (m < M) {
-          int mo = m;
-          if (cv.on) {
-            int n_, rem, hh, ww;
-            fast_divmod(m, cv.Hc * cv.Wc, cv.rhw, n_, rem);
-            fast_divmod(rem, cv.Wc, cv.rw, hh, ww);
-            mo = (n_ * cv.OH + 2 * hh + cv.ph) * cv.OW + 2 * ww + cv.pw;
-          }
-          e_off[k] = (unsigned)mo * (unsigned)ldy + (unsigned)e_c;
-          e_yv[k] = *reinterpret_cast<const uint4*>(bn.y + e_off[k]);
-          if (accumulate) e_ev[k] = *reinterpret_cast<const uint4*>((bn.addend ? bn.addend : reinterpret_cast<const bf16_t*>(Yv)) + e_off[k]);
-          e_mk[k] = bn.mask ? (unsigned)bn.mask[e_off[k] >> 3] : 0xffu;
-        }
-      }
-    };
-    if constexpr (BNEPI) e_load(0);
-    __syncthreads();                                  // every wave is done with the operand ring
-#pragma unroll
-    for (int b = 0; b < PT; ++b) {
-      const int pl = wm * (PT * 16) + b * 16 + (lane & 15);
-#pragma unroll
-      for (int a = 0; a < CT; ++a) {
-        const int cl = wn * (CT * 16) + a * 16 + cq;
-        uint2 o;
-        o.x = pack_bf2(acc[a][b][0], acc[a][b][1]);
-        o.y = pack_bf2(acc[a][b][2], acc[a][b][3]);
-        *reinterpret_cast<uint2*>(smem + pl * OLD + cl * 2) = o;
-        if (stat_sum && !accumulate && m0 + pl < M) {   // statistics of the values as stored (bf16-rounded)
-          const float r0 = lo2f(o.x), r1 = hi2f(o.x);
-          const float r2 = lo2f(o.y), r3 = hi2f(o.y);
-          ssum[a][0] += r0; ssum[a][1] += r1; ssum[a][2] += r2; ssum[a][3] += r3;
-          ssq[a][0] += r0 * r0; ssq[a][1] += r1 * r1; ssq[a][2] += r2 * r2; ssq[a][3] += r3 * r3;
-        }
-      }
-    }
-    __syncthreads();
-    constexpr int CPR = BN / 8;                       // 16-byte chunks per row
-    bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
-    if constexpr (BNEPI) {   // data gradient of a BatchNorm unit's output: mask, store g, partial sums of g and g xhat
-      constexpr int RG = E_RG, ITER = E_ITER, NB = E_NB;
-      static_assert(BM % RG == 0 && ITER % NB == 0 && RG * BN * 4 <= BM * (BN * 2 + 16), "epilogue geometry");
-      const int ch = e_ch, rg = e_rg, c = e_c;
-      float mu[8], rs[8], s0[8], s1[8], s2[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { mu[j] = bn.mean[c + j]; rs[j] = bn.rstd[c + j]; s0[j] = s1[j] = s2[j] = 0.f; }
-#pragma unroll
-      for (int it0 = 0; it0 < ITER; it0 += NB) {
-        if (it0 > 0) e_load(it0);                     // (256 x 128 tiles only: the second batch of rows)
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-          if (e_off[k] != 0xffffffffu) {
-            const int row = rg + (it0 + k) * RG;
-            uint4 v = *reinterpret_cast<const uint4*>(smem + row * OLD + ch * 16);
-            float g8[8], y8[8];
-            if (accumulate) {                         // gradient fan-in: float32 add, one rounding (as the plain path below)
-              unpack_bf8(v, g8);
-              unpack_bf8(e_ev[k], y8);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) g8[j] += y8[j];
-              v = pack_bf8(g8);
-            }
-            unsigned w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              w4[q] = (((e_mk[k] >> (2 * q)) & 1u) ? (w4[q] & 0xffffu) : 0u) | (((e_mk[k] >> (2 * q + 1)) & 1u) ? (w4[q] & 0xffff0000u) : 0u);
-            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-            *reinterpret_cast<uint4*>(Y + e_off[k]) = v;
-            unpack_bf8(v, g8);
-            unpack_bf8(e_yv[k], y8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s0[j] += g8[j]; s1[j] += g8[j] * ((y8[j] - mu[j]) * rs[j]); }
-            if (bn.y2) {                              // shortcut BatchNorm of a down-sampling block (3 units per step): loaded in place
-              unpack_bf8(*reinterpret_cast<const uint4*>(bn.y2 + e_off[k]), y8);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) s2[j] += g8[j] * ((y8[j] - bn.mean2[c + j]) * bn.rstd2[c + j]);
-            }
-          }
-        }
-      }
-      float* red = reinterpret_cast<float*>(smem);    // [RG][BN], one quantity at a time
-      const int nq = bn.y2 ? 3 : 2;
-      for (int q = 0; q < nq; ++q) {
-        __syncthreads();                              // the staged tile (q = 0) / the previous quantity has been read
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[rg * BN + ch * 8 + j] = q == 0 ? s0[j] : (q == 1 ? s1[j] : s2[j]);
-        __syncthreads();
-        for (int cl = tid; cl < BN; cl += NW * 64) {
-          float t = 0.f;
-#pragma unroll 8
-          for (int r = 0; r < RG; ++r) t += red[r * BN + cl];
-          bn.partial[((size_t)prow * 3 + q) * ldy + n0 + cl] = t;
-        }
-      }
-      return;
-    }
-    for (int i = tid; i < BM * CPR; i += NW * 64) {
-      const int row = i / CPR, ch = i - row * CPR;
-      const int m = m0 + row;
-      if (m < M) {
-        uint4 v = *reinterpret_cast<const uint4*>(smem + row * OLD + ch * 16);
-        int mo = m;
-        if (cv.on) {                                  // parity class: pixel (n, h', w') of the class grid -> (n, 2h' + ph, 2w' + pw) of dX
-          int n_, rem, hh, ww;
-          fast_divmod(m, cv.Hc * cv.Wc, cv.rhw, n_, rem);
-          fast_divmod(rem, cv.Wc, cv.rw, hh, ww);
-          mo = (n_ * cv.OH + 2 * hh + cv.ph) * cv.OW + 2 * ww + cv.pw;
-        }
-        bf16_t* yp = Y + (size_t)mo * ldy + n0 + ch * 8;
-        if (accumulate) {                             // gradient fan-in: y += tile (float32 add, one rounding)
-          float a8[8], b8[8];
-          unpack_bf8(v, a8);
-          unpack_bf8(*reinterpret_cast<const uint4*>(bn.addend ? bn.addend + ((size_t)mo * ldy + n0 + ch * 8) : yp), b8);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a8[j] += b8[j];
-          v = pack_bf8(a8);
-        }
-        *reinterpret_cast<uint4*>(yp) = v;
-      }
-    }
-  }
-
-  if (stat_sum) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
-    __syncthreads();                                  // every wave is done with the staged output tile
-    float* red = reinterpret_cast<float*>(smem);      // [2][WM][BN]
-#pragma unroll
-    for (int a = 0; a < CT; ++a)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float s = ssum[a][j], q = ssq[a][j];
-        s = row16_sum(s);
-        q = row16_sum(q);
-        if ((lane & 15) == 0) {
-          const int cl = wn * (CT * 16) + a * 16 + cq + j;
-          red[wm * BN + cl] = s;
-          red[(WM + wm) * BN + cl] = q;
-        }
-      }
-    __syncthreads();
-    for (int cl = tid; cl < BN; cl += NW * 64) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) { s += red[w * BN + cl]; q += red[(WM + w) * BN + cl]; }
-      stat_sum[(size_t)tile_m * Kout + n0 + cl] = s;
-      stat_sq[(size_t)tile_m * Kout + n0 + cl] = q;
-    }
-  }
-}
 
 
 // Forward / data-gradient implicit GEMM.  BM pixels x BN channels per 256-thread workgroup; a 3-stage LDS ring filled by LDS-DMA
@@ -1348,6 +1037,7 @@ int pick_strip(const Gather& g, int Kout, bool f32, int* bnp = nullptr) {
   return bm;
 }
 int stat_rows_for(const Gather& g, int Kout) {
+  if (const int pb = yolo_pstrip_plan(g, Kout, false, nullptr)) return (g.M + pb - 1) / pb;
   const int sb = pick_strip(g, Kout, false);
   if (sb) return (g.M + sb - 1) / sb;
   const TileCfg t = pick_tile(g.M, Kout);
@@ -1452,6 +1142,9 @@ template <bool F32>
 int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, const Epi& e,
                int Kout, hipStream_t st) {
   int sbn = 0;
+  if constexpr (!F32) {
+    if (!bias && yolo_pstrip_plan(g, Kout, false, nullptr)) return yolo_pstrip_launch(g, w, y, ldy, accumulate, e, Kout, st);
+  }
   if (const int sb = pick_strip(g, Kout, F32, &sbn)) {
     const bool wide = sbn == 128;
     if (sb == 64) return wide ? launch_strip<64, 128, 4>(g, w, y, ldy, accumulate, e, Kout, st)
@@ -1491,6 +1184,8 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "wgrad_ring")) { YOLO_CHECK_ARG(value == 2 || value == 3, "wgrad_ring"); g_wgrad_ring = value; }
   else if (!strcmp(name, "wgrad_xcd")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_xcd"); g_wgrad_xcd = value; }
   else if (!strcmp(name, "strip_ws")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 3, "strip_ws"); g_strip_ws = value; }
+  else if (!strcmp(name, "ps_depth")) { YOLO_CHECK_ARG(value == 1 || value == 3, "ps_depth"); g_ps_depth = value; }
+  else if (!strcmp(name, "pstrip")) { YOLO_CHECK_ARG(value >= -1 && value <= 2, "pstrip"); g_pstrip = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
   return YOLO_OK;
@@ -1502,6 +1197,29 @@ extern "C" int yolo_conv2d_stat_rows(const yolo_conv_problem* p) {
   if (yolo_stem_applies(p)) return yolo_stem_stat_rows(p);
   static const char dummy = 0;
   return stat_rows_for(fwd_gather(p, &dummy, &dummy), p->Cout);
+}
+
+extern "C" int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info) {
+  YOLO_CHECK_ARG(info != nullptr, "null info");
+  int rc = check_problem(p);
+  if (rc) return rc;
+  for (int i = 0; i < 8; ++i) info[i] = 0;
+  if (yolo_stem_applies(p)) { info[0] = 3; info[4] = yolo_stem_stat_rows(p); return YOLO_OK; }
+  static const char dummy = 0;
+  const Gather g = fwd_gather(p, &dummy, &dummy);
+  PsPlanOut pl;
+  if (yolo_pstrip_plan(g, p->Cout, false, &pl)) {
+    info[0] = 2; info[1] = pl.bm; info[2] = pl.bn; info[3] = pl.tstride; info[4] = pl.tiles; info[5] = (int32_t)pl.lds; info[6] = pl.ring;
+    return YOLO_OK;
+  }
+  int sbn = 0;
+  if (const int sb = pick_strip(g, p->Cout, false, &sbn)) {
+    info[0] = 1; info[1] = sb; info[2] = sbn; info[3] = sb; info[4] = (g.M + sb - 1) / sb * (p->Cout / sbn);
+    return YOLO_OK;
+  }
+  const TileCfg t = pick_tile(g.M, p->Cout);
+  info[1] = t.bm; info[2] = t.bn; info[3] = t.bm; info[4] = (g.M + t.bm - 1) / t.bm * (p->Cout / t.bn);
+  return YOLO_OK;
 }
 
 extern "C" int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd,

@@ -52,6 +52,18 @@ def conv2d_stat_rows(p):
     return r
 
 
+CONV_FAMILIES = ('igemm', 'strip', 'pstrip', 'stem')
+
+
+def conv2d_fwd_plan(p):
+    """the kernel yolo_conv2d_fwd would launch for p under the current tuning (yolo_conv2d_fwd_plan): dict(family, bm, bn, tile_pixels,
+    workgroups, lds_bytes, ring)"""
+    info = (C.c_int32 * 8)()
+    check(_lib.load().yolo_conv2d_fwd_plan(C.byref(p), info), 'yolo_conv2d_fwd_plan')
+    return dict(family=CONV_FAMILIES[info[0]], bm=info[1], bn=info[2], tile_pixels=info[3], workgroups=info[4], lds_bytes=info[5],
+                ring=info[6])
+
+
 def conv2d_fwd(p, src1, w_fwd, y, src0=None, bias=None, stat_sum=None, stat_sq=None):
     check(_lib.load().yolo_conv2d_fwd(C.byref(p), _p(src0), _p(src1), _p(w_fwd), _p(bias), _p(y),
                                       1 if y.dtype == torch.float32 else 0, _p(stat_sum), _p(stat_sq), _stream()), 'yolo_conv2d_fwd')
