@@ -86,7 +86,7 @@ int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info8);
  * "stem_direct": 1 (default) / 0 the RGB stem (Cin 8, Cout 64, 3x3 stride 2) on its row-walking kernel or on the implicit GEMM (changes yolo_conv2d_stat_rows);
  * "dw_tiled": 1 (default) / 0 the mixed depthwise forward / data gradient on its tiled kernel or on the row-tile kernel, > 1 = workgroups per
  * 64-channel slab of the tiled kernel's persistent grid (default 512);
- * "pstrip": -1 auto (default) / 0 never / 1 + v force variant v (0: 352 pixels x 64 channels, 1: 176 x 128) of the one-tile-per-CU
+ * "pstrip": -1 auto (default) / 0 never / 1 + v force variant v (0: 352 pixels x 64 channels, 1: 176 x 128, 2: 384 x 64, 3: 192 x 128) of the one-tile-per-CU
  * kernel for 3x3 stride-1 convolutions (conv_pstrip.hip; changes yolo_conv2d_stat_rows);
  * "strip_ws": 0 auto / 2 / 3 weight-ring stages; "s2_classes": 0 / 1 stride-2 data gradient as four dense parity classes;
  * "wgrad_target": workgroups the split-K plan aims at (64..4096, default 384; changes yolo_conv2d_wgrad_workspace_bytes);

@@ -47,7 +47,7 @@ def forced():
 
 def expected_rows(M, Cout, variant, H, W):
     """statistics rows of the forced variant (None: the variant does not take the shape) -- mirrors ps_plan_variant's tile stride"""
-    bm, bn = ((352, 64), (176, 128))[variant]
+    bm, bn = ((352, 64), (176, 128), (384, 64), (192, 128))[variant]
     if Cout % bn:
         return None
     tn = Cout // bn
@@ -73,7 +73,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 @pytest.mark.parametrize('case', CASES, ids=[str(c) for c in CASES])
 def test_pstrip_fwd_dgrad(dev, forced, case, variant):
     from yolov3_tensorflow_amd import ops
@@ -118,7 +118,7 @@ def test_pstrip_fwd_dgrad(dev, forced, case, variant):
     torch.cuda.synchronize()
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
 
-    if Cin % 64 == 0 and Cin % (64 if variant == 0 else 128) == 0:
+    if Cin % 64 == 0 and Cin % (64 if variant in (0, 2) else 128) == 0:
         dyd = dy.to(dev)
         w_dg = torch.empty(Cin, 3, 3, Cout, dtype=ACT(), device=dev)
         ops.repack_dgrad_weights(w_fwd, w_dg, Cout, 3, 3, Cin)
@@ -135,6 +135,9 @@ def test_pstrip_fwd_dgrad(dev, forced, case, variant):
     (6, 13, 13, 128, 128, 0, False, True, False),
     (2, 52, 52, 128, 128, 1, True, True, False),
     (9, 13, 13, 128, 256, 1, False, False, False),
+    (8, 26, 26, 256, 128, 2, True, True, True),
+    (3, 52, 52, 128, 128, 2, False, True, False),
+    (5, 26, 26, 128, 256, 3, True, True, False),
 ])
 def test_pstrip_dgrad_with_bn_reduce_epilogue(dev, forced, case):
     """as test_kernels_gpu.py::test_dgrad_with_bn_reduce_epilogue, on the big-tile kernel: the fused launch stores the masked gradient of the

@@ -39,5 +39,7 @@ t0 = s[:, 0].min()
 print('workgroup start spread: %.0f cycles; whole workgroup median %.0f, max end %.0f' % (float((s[:, 0] - t0).max()), float((s[:, 7] - s[:, 0]).median()), float((s[:, 7] - t0).max())))
 for i in range(1, 8):
     print('  %-28s %8.0f' % (names[i], float((s[:, i] - s[:, i - 1]).median())))
+print('  epilogue: first sync %.0f, staging %.0f, sync %.0f, store loop %.0f, statistics %.0f' % tuple(
+    float((s[:, i] - s[:, j]).median()) for i, j in ((13, 6), (14, 13), (15, 14), (16, 15), (7, 16))))
 print('  one K step (slice 1, tap 4): DMA issue %.0f, reads + MFMAs %.0f, vmcnt wait %.0f, barrier %.0f' % tuple(
     float((s[:, i] - s[:, i - 1]).median()) for i in (9, 10, 11, 12)))

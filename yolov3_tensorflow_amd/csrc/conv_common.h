@@ -4,6 +4,9 @@
 #include "common.h"
 #include <type_traits>
 #include <string.h>
+#ifndef PS_STAMP
+#define PS_STAMP(i) do {} while (0)      // (diagnostic builds of conv_pstrip.hip define it: s_memtime stamps)
+#endif
 
 namespace yoloconv {
 
@@ -138,11 +141,13 @@ constexpr int BK = 64;  // K elements per stage
 // Tile epilogue shared by the conv kernels: lane holds channels co..co+3 (rows of D) of pixel (column of D); acc[a][b] = channel tile a x
 // pixel tile b of this wave (wave grid WM pixels x WN channels).  bf16 outputs are staged through LDS (the operand buffers are free by
 // then), optional BatchNorm partial statistics go to one row per pixel tile.
-template <int BM, int BN, int NW, int WM, int WN, int PT, int CT, bool OUT_F32, bool BNEPI = false>
+// (SG > 1: the waves of SG k-groups share the pixel / channel positions (wm, wn); group sg stages only its pixel fragments [b_lo, b_hi) and
+// the statistics of the groups are summed)
+template <int BM, int BN, int NW, int WM, int WN, int PT, int CT, bool OUT_F32, bool BNEPI = false, int SG = 1>
 __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem, int M, int m0, int n0, int tile_m, const float* __restrict__ bias,
                                               void* __restrict__ Yv, int ldy, int accumulate, float* __restrict__ stat_sum,
                                               float* __restrict__ stat_sq, int Kout, int tid, int lane, int wm, int wn, const ClassView& cv,
-                                              const BnEpi& bn, int prow, bool has_acc = true) {
+                                              const BnEpi& bn, int prow, int sg = 0, int b_lo = 0, int b_hi = PT) {
   const int cq = (lane >> 4) * 4;
   float ssum[CT][4], ssq[CT][4];
 #pragma unroll
@@ -203,9 +208,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
     };
     if constexpr (BNEPI) e_load(0);
     __syncthreads();                                  // every wave is done with the operand ring
-    if (has_acc) {                                    // (waves of a K group that handed its partial sums over hold nothing to stage)
+    PS_STAMP(13);
 #pragma unroll
     for (int b = 0; b < PT; ++b) {
+      if (b < b_lo || b >= b_hi) continue;            // (a k-group stages the fragments it holds the final sums of)
       const int pl = wm * (PT * 16) + b * 16 + (lane & 15);
 #pragma unroll
       for (int a = 0; a < CT; ++a) {
@@ -222,8 +228,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
         }
       }
     }
-    }
+    PS_STAMP(14);
     __syncthreads();
+    PS_STAMP(15);
     constexpr int CPR = BN / 8;                       // 16-byte chunks per row
     bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
     if constexpr (BNEPI) {   // data gradient of a BatchNorm unit's output: mask, store g, partial sums of g and g xhat
@@ -309,9 +316,12 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
     }
   }
 
+  PS_STAMP(16);
   if (stat_sum) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
     __syncthreads();                                  // every wave is done with the staged output tile
-    float* red = reinterpret_cast<float*>(smem);      // [2][WM][BN]
+    float* red = reinterpret_cast<float*>(smem);      // [2][SG * WM][BN]
+    constexpr int WMS = SG * WM;
+    const int wms = sg * WM + wm;
 #pragma unroll
     for (int a = 0; a < CT; ++a)
 #pragma unroll
@@ -319,17 +329,17 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
         float s = ssum[a][j], q = ssq[a][j];
         s = row16_sum(s);
         q = row16_sum(q);
-        if ((lane & 15) == 0 && has_acc) {
+        if ((lane & 15) == 0) {
           const int cl = wn * (CT * 16) + a * 16 + cq + j;
-          red[wm * BN + cl] = s;
-          red[(WM + wm) * BN + cl] = q;
+          red[wms * BN + cl] = s;
+          red[(WMS + wms) * BN + cl] = q;
         }
       }
     __syncthreads();
     for (int cl = tid; cl < BN; cl += NW * 64) {
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { s += red[w * BN + cl]; q += red[(WM + w) * BN + cl]; }
+      for (int w = 0; w < WMS; ++w) { s += red[w * BN + cl]; q += red[(WMS + w) * BN + cl]; }
       stat_sum[(size_t)tile_m * Kout + n0 + cl] = s;
       stat_sq[(size_t)tile_m * Kout + n0 + cl] = q;
     }

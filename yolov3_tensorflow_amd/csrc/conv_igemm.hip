@@ -1185,7 +1185,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "wgrad_xcd")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_xcd"); g_wgrad_xcd = value; }
   else if (!strcmp(name, "strip_ws")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 3, "strip_ws"); g_strip_ws = value; }
   else if (!strcmp(name, "ps_depth")) { YOLO_CHECK_ARG(value == 1 || value == 3, "ps_depth"); g_ps_depth = value; }
-  else if (!strcmp(name, "pstrip")) { YOLO_CHECK_ARG(value >= -1 && value <= 2, "pstrip"); g_pstrip = value; }
+  else if (!strcmp(name, "pstrip")) { YOLO_CHECK_ARG(value >= -1 && value <= 4, "pstrip"); g_pstrip = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
   return YOLO_OK;

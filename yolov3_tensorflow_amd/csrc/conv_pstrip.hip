@@ -17,6 +17,24 @@
 // * Strip slices are double-buffered (slice c+1 streams in behind the K steps of slice c), the weight tiles run through a ring of
 //   RING stages with counted s_waitcnt vmcnt, the first fragments of K step s+1 are read before the barrier that ends K step s.
 // * Epilogue: conv_common.h tile_epilogue (bf16 tile through LDS, BatchNorm statistics / fused BatchNorm-backward reduce).
+namespace {
+// Diagnostic builds only (make EXTRA_conv_pstrip=-DPS_STAMPS; tools/probes/pstrip_stamps.py): s_memtime stamps of wave 0 of every workgroup.
+// In the product build no stamp executes and the symbol below does not exist.
+#ifdef PS_STAMPS
+__device__ unsigned long long* g_ps_stamps = nullptr;
+#define PS_STAMP(i)                                                                                      \
+  do {                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    unsigned long long t_;                                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (g_ps_stamps && threadIdx.x == 0) g_ps_stamps[blockIdx.x * 32 + (i)] = t_;                        \
+  } while (0)
+#else
+#define PS_STAMP(i) do {} while (0)
+#endif
+
+}  // namespace
 #include "conv_common.h"
 
 namespace {
@@ -38,33 +56,23 @@ constexpr int PS_NPW = 10;                 // strip pieces per wave and slice (1
 // weights of tap 8, issued in tap 5 or 6) also covers the whole slice and the barrier there publishes it before tap 8 reads ahead into it
 __host__ __device__ constexpr int ps_ns(int t) { return t < 5 ? 2 : 0; }
 
-// Diagnostic builds only (make EXTRA_conv_pstrip=-DPS_STAMPS; tools/probes/pstrip_stamps.py): s_memtime stamps of wave 0 of every workgroup.
-// In the product build no stamp executes and the symbol below does not exist.
-#ifdef PS_STAMPS
-__device__ unsigned long long* g_ps_stamps = nullptr;
-#define PS_STAMP(i)                                                                                      \
-  do {                                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    unsigned long long t_;                                                                               \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                   \
-    if (g_ps_stamps && threadIdx.x == 0) g_ps_stamps[blockIdx.x * 32 + (i)] = t_;                        \
-  } while (0)
-#else
-#define PS_STAMP(i) do {} while (0)
-#endif
+// LDS-DMA instructions a wave has issued BEHIND its pieces of K step s+1 when it waits for them (end of the K step of tap t): the strip
+// pieces of tap t-(ring-2) .. t and the weights of the ring-2 K steps in between (nwp pieces each)
+__host__ __device__ constexpr int ps_behind(int t, int ring, int nwp) {
+  int n = (ring - 2) * nwp;
+  for (int j = 0; j <= ring - 2; ++j) n += ps_ns((t + 9 - j) % 9);
+  return n;
+}
 
 template <int N_> __device__ __forceinline__ void ps_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-template <int KG, int MW, int NV, int PT, int RING, bool BNEPI, int DEPTH>
+template <int KG, int MW, int NV, int PT, int CT, int RING, bool BNEPI>
 __global__ __launch_bounds__(512) void conv3x3_pstrip_kernel(PStripArgs a, void* __restrict__ Yv, int ldy, int accumulate,
                                                             float* __restrict__ stat_sum, float* __restrict__ stat_sq, int Kout, int tiles_n,
                                                             BnEpi bnepi) {
-  static_assert(KG * MW * NV == 8 && (KG == 1 || KG == 2), "8 waves");
+  static_assert(KG * MW * NV == 8 && KG == 2, "8 waves in two k-groups");
   static_assert(RING == 3 || RING == 4, "weight ring depth");
-  static_assert(DEPTH >= 1 && DEPTH <= 4 && DEPTH < PT - 1, "fragment read-ahead");
-  constexpr int CT = 2, BM = MW * PT * 16, BN = NV * 32;
-  constexpr int SUBS = KG == 1 ? 2 : 1;              // 32-deep MFMA sub-steps of a K step that one wave computes
+  constexpr int BM = MW * PT * 16, BN = NV * CT * 16;
   constexpr int NWP = BN / 64;                       // weight pieces (8 rows x 128 B) per wave and K step
   constexpr int W_STAGE = BN * 128;
   static_assert(NWP >= 1, "channel tile too small");
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(512) void conv3x3_pstrip_kernel(PStripArgs a, void*
   // LDS: [strip buffer 0][strip buffer 1][weight ring].  Padding pieces (they keep the vmcnt arithmetic uniform) land in the lead pad
   // of strip buffer 0: out-of-range sources write zeros, which is what that KiB holds anyway.
   const int SB = a.strip_bytes;
-  const int ring0 = 2 * SB, dump0 = 0, lds_end = ring0 + RING * W_STAGE;
+  const int ring0 = 2 * SB, dump0 = 0;
 
   PS_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,29 +110,6 @@ __global__ __launch_bounds__(512) void conv3x3_pstrip_kernel(PStripArgs a, void*
   const int cchunk = (lane & 7) ^ lrow;
   const int wp8 = a.Wp >> 3;
 
-  // source offset (slice 0) of this lane in each of the wave's strip pieces, or an out-of-range offset (-> zeros): piece i = wave + 8 k
-  // holds LDS rows 8 (i - 1) .. + 7 = columns 8 xg .. + 7 of strip line l.  (l, xg) and the line's (image, row) advance piece by piece
-  // in scalar registers; the lane adds its column and chunk.
-  unsigned spoff[PS_NPW];
-  {
-    int l = 0, xg = wave - 1;                          // piece 0 (wave 0, k = 0) is the lead pad: xg = -1 marks it
-    while (xg >= wp8) { xg -= wp8; ++l; }
-    int n = n_first, y = y_first - 1 + l;              // extended line e0 - 1 + l
-    if (y < 0) { y += H1; --n; }
-    while (y >= H1) { y -= H1; ++n; }
-    const unsigned lane_part = (unsigned)((lrow * a.C + cchunk * 8) * 2);
-#pragma unroll
-    for (int k = 0; k < PS_NPW; ++k) {
-      const int x = xg * 8 + lrow;
-      const bool line_ok = xg >= 0 && n >= 0 && n < a.N && y < a.H && (wave + 8 * k) < a.npieces;
-      const unsigned base = (unsigned)((((n * a.H + y) * a.W + xg * 8) * a.C) * 2);
-      spoff[k] = (line_ok && x < a.W) ? base + lane_part : 0x80000000u;
-      // next piece of this wave: 8 pieces further
-      if (xg < 0) { xg += 8; } else { xg += a.dr8; l += a.dq8; y += a.dq8; }
-      while (xg >= wp8) { xg -= wp8; ++l; ++y; }
-      while (y >= H1) { y -= H1; ++n; }
-    }
-  }
   unsigned wbase[NWP];
 #pragma unroll
   for (int j = 0; j < NWP; ++j) wbase[j] = (unsigned)(((n0 + (wave * NWP + j) * 8 + lrow) * a.Kg + cchunk * 8) * 2);
@@ -146,10 +131,7 @@ __global__ __launch_bounds__(512) void conv3x3_pstrip_kernel(PStripArgs a, void*
   };
   auto rd = [&](int addr) -> bf16x8_t { return *reinterpret_cast<const bf16x8_t*>(smem + addr); };
 
-  PS_STAMP(1);
-  // ---- prologue: slice 0 of the strip, K steps 0 .. RING-2 of the weights; the per-lane fragment addresses are worked out while they fly ----
-#pragma unroll
-  for (int k = 0; k < PS_NPW; ++k) issue_strip(k, spoff[k], 0, 0);
+  // ---- prologue: K steps 0 .. RING-2 of the weights and slice 0 of the strip are requested as early as their addresses are known ----
   {
     int cc = 0, tap = 0;
 #pragma unroll
@@ -158,6 +140,31 @@ __global__ __launch_bounds__(512) void conv3x3_pstrip_kernel(PStripArgs a, void*
       if (++tap == 9) { tap = 0; ++cc; }
     }
   }
+  // source offset (slice 0) of this lane in each of the wave's strip pieces, or an out-of-range offset (-> zeros): piece i = wave + 8 k
+  // holds LDS rows 8 (i - 1) .. + 7 = columns 8 xg .. + 7 of strip line l.  (l, xg) and the line's (image, row) advance piece by piece
+  // in scalar registers; the lane adds its column and chunk.
+  unsigned spoff[PS_NPW];
+  {
+    int l = 0, xg = wave - 1;                          // piece 0 (wave 0, k = 0) is the lead pad: xg = -1 marks it
+    while (xg >= wp8) { xg -= wp8; ++l; }
+    int n = n_first, y = y_first - 1 + l;              // extended line e0 - 1 + l
+    if (y < 0) { y += H1; --n; }
+    while (y >= H1) { y -= H1; ++n; }
+    const unsigned lane_part = (unsigned)((lrow * a.C + cchunk * 8) * 2);
+#pragma unroll
+    for (int k = 0; k < PS_NPW; ++k) {
+      const int x = xg * 8 + lrow;
+      const bool line_ok = xg >= 0 && n >= 0 && n < a.N && y < a.H && (wave + 8 * k) < a.npieces;
+      const unsigned base = (unsigned)((((n * a.H + y) * a.W + xg * 8) * a.C) * 2);
+      spoff[k] = (line_ok && x < a.W) ? base + lane_part : 0x80000000u;
+      issue_strip(k, spoff[k], 0, 0);
+      // next piece of this wave: 8 pieces further
+      if (xg < 0) { xg += 8; } else { xg += a.dr8; l += a.dq8; y += a.dq8; }
+      while (xg >= wp8) { xg -= wp8; ++l; ++y; }
+      while (y >= H1) { y -= H1; ++n; }
+    }
+  }
+  PS_STAMP(1);
 
   // pixel fragments: LDS byte address of (pixel, k chunk of this lane) for the three tap columns, tap row 0, strip buffer 0.  Each
   // thread decodes ONE pixel of the tile into its LDS row (a table in strip buffer 1, which nothing uses before K step 0), every lane
@@ -204,101 +211,66 @@ __global__ __launch_bounds__(512) void conv3x3_pstrip_kernel(PStripArgs a, void*
   asm volatile("" ::: "memory");
 
   PS_STAMP(2);
-  // K step being issued (RING-1 ahead of the one being computed) and the ring slots
-  int icc = (RING - 1) / 9, itap = (RING - 1) % 9, islot = RING - 1;
-  int cslot = 0;                                        // slot of the K step being computed
-  bf16x8_t wf[SUBS][CT], pq[DEPTH][SUBS];               // operands of the current K step that were read ahead: weights, first DEPTH pixel fragments
-#pragma unroll
-  for (int u = 0; u < SUBS; ++u) {
-#pragma unroll
-    for (int c = 0; c < CT; ++c) wf[u][c] = rd(wa[c] ^ (u << 6));
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) pq[d][u] = rd(pa[0][d] ^ (u << 6));
-  }
-
+  // ---- K loop: two phases per K step, the two k-groups half a step apart (the 8-phase GEMM structure of the CDNA guide) ----
+  // LOAD phase: the wave reads the K step's 2 weight + PT pixel fragments into registers and issues its share of the LDS-DMA for two K
+  // steps ahead; MFMA phase: 2 * PT MFMAs back to back at raised priority, no LDS or memory instruction in between.  A raw s_barrier
+  // ends every phase.  Group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA cluster while the other loads:
+  //   group 0:  LOAD(0) | MFMA(0) | LOAD(1) | MFMA(1) | ...            (phase 2s, 2s+1)
+  //   group 1:          | LOAD(0) | MFMA(0) | LOAD(1) | MFMA(1) | ...  (phase 2s+1, 2s+2)
+  // Ring slot (s % RING) is read in phases 2s and 2s+1; K step s+2 is issued in LOAD(s) into the slot of K step s-1 (RING = 3), behind the
+  // barrier that ended phase 2s-1; every wave waits for its own pieces of K step s+1 before the barrier that starts phase 2s+2 (group 0 at
+  // the end of MFMA(s), group 1 at the end of LOAD(s): the same counted vmcnt either way).  The next strip slice is issued in the LOAD
+  // phases of taps 0..4 and is covered by those waits before tap 8 ends (vmcnt retires in order).
+  int icc = (RING - 1) / 9, itap = (RING - 1) % 9, islot = RING - 1;   // K step being issued (RING-1 ahead) and its slot
+  int cslot = 0;                                                       // slot of the K step being loaded
+  if (g == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
   int s = 0;
   for (int cc = 0; cc < nchunk; ++cc) {
-    const int sbuf = (cc & 1) * SB, nbuf = ((cc + 1) & 1) * SB;
+    const int sbuf = (cc & 1) * SB;
     auto stage = [&](auto TC) {
       constexpr int T = decltype(TC)::value;
       constexpr int tr = T / 3, ts = T % 3;
-      constexpr int TN = (T + 1) % 9, trn = TN / 3, tsn = TN % 3;
-      constexpr int TPv = (T + 8) % 9;
-      // operands of K steps further ahead: weights of K step s + RING - 1, this tap's share of the next strip slice.  An LDS-DMA
-      // instruction holds its wave's issue for ~100 cycles, and the two waves of a SIMD (k-groups 0 and 1) would do that at the same
-      // time, right behind the barrier, with the MFMA pipe idle: group 0 issues before its MFMAs, group 1 behind them (RING = 3: in
-      // the middle -- the K step's weights are waited for at its end), so that one of the two always has MFMAs to issue.
       constexpr int k0 = 2 * T;                         // first strip piece of this tap (ps_ns: 2,2,2,2,2,0,0,0,0)
-      auto dma = [&]() {
-#ifndef PS_NODMA
-        issue_weights(s + RING - 1, icc, itap, islot);
-        if (++itap == 9) { itap = 0; ++icc; }
-        if (++islot == RING) islot = 0;
-#pragma unroll
-        for (int q = 0; q < ps_ns(T); ++q) issue_strip(k0 + q, spoff[k0 + q], cc + 1, (cc + 1) & 1);
-#endif
-      };
+      // -------- LOAD --------
       if (cc == 1 && T == 4) PS_STAMP(8);
-      if (g == 0) dma();
-      if (cc == 1 && T == 4) PS_STAMP(9);
       const int soff = sbuf + tr * WpB;
-      const int soffn = (T == 8 ? nbuf : sbuf) + trn * WpB;
-      int nslot = cslot + 1;
-      if (nslot == RING) nslot = 0;
-      const int woffn = nslot * W_STAGE;
-      bf16x8_t pf[PT][SUBS], wfn[SUBS][CT], pn[DEPTH][SUBS];
+      const int woff = cslot * W_STAGE;
+      bf16x8_t wf[CT], pf[PT];
 #pragma unroll
-      for (int u = 0; u < SUBS; ++u)
+      for (int c = 0; c < CT; ++c) wf[c] = rd(wa[c] + woff);
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) pf[d][u] = pq[d][u];
-      // fragment b + DEPTH (of the next K step once this one runs out) is requested before the MFMAs of fragment b; the order is pinned
-      // (hipcc otherwise sinks every read to one fragment ahead of its use, which two waves per SIMD do not cover)
-#pragma unroll
-      for (int b = 0; b < PT; ++b) {
-#pragma unroll
-        for (int u = 0; u < SUBS; ++u) {
-          if (b + DEPTH < PT) pf[b + DEPTH][u] = rd((pa[ts][b + DEPTH] ^ (u << 6)) + soff);
-          else pn[b + DEPTH - PT][u] = rd((pa[tsn][b + DEPTH - PT] ^ (u << 6)) + soffn);
-        }
-        if (b == PT - DEPTH - 1) {
-#pragma unroll
-          for (int u = 0; u < SUBS; ++u)
-#pragma unroll
-            for (int c = 0; c < CT; ++c) wfn[u][c] = rd((wa[c] ^ (u << 6)) + woffn);
-        }
-#pragma unroll
-        for (int u = 0; u < SUBS; ++u)
-#pragma unroll
-          for (int c = 0; c < CT; ++c) acc[c][b] = YOLO_MFMA_16x16x32(wf[u][c], pf[b][u], acc[c][b]);
-        if (b == PT - DEPTH - 1) __builtin_amdgcn_sched_group_barrier(0x100, SUBS * (1 + CT), 0);       // DS reads
-        else __builtin_amdgcn_sched_group_barrier(0x100, SUBS, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, SUBS * CT, 0);                                       // MFMAs
-        if (RING == 3 && b == PT / 2 && g != 0) dma();
-      }
-      if (RING != 3 && g != 0) dma();
-      // the weights of K step s + 2 have landed (they are read ahead at the end of K step s + 1, behind the barrier below); every older
-      // piece -- in particular the whole next strip slice by the end of tap 7 -- has landed with them (vmcnt retires in order)
-      if (cc == 1 && T == 4) PS_STAMP(10);
+      for (int b = 0; b < PT; ++b) pf[b] = rd(pa[ts][b] + soff);
 #ifndef PS_NODMA
-      if constexpr (RING == 3) ps_wait_vmcnt<ps_ns(T)>();
-      else ps_wait_vmcnt<ps_ns(TPv) + NWP + ps_ns(T)>();
+      issue_weights(s + RING - 1, icc, itap, islot);
+      if (++itap == 9) { itap = 0; ++icc; }
+      if (++islot == RING) islot = 0;
+#pragma unroll
+      for (int q = 0; q < ps_ns(T); ++q) issue_strip(k0 + q, spoff[k0 + q], cc + 1, (cc + 1) & 1);
+      if (g == 1) ps_wait_vmcnt<ps_behind(T, RING, NWP)>();
+#endif
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): every fragment is in its registers (the MFMA cluster waits for nothing)
+      if (cc == 1 && T == 4) PS_STAMP(9);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (cc == 1 && T == 4) PS_STAMP(10);
+      // -------- MFMA --------
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int b = 0; b < PT; ++b)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c][b] = YOLO_MFMA_16x16x32(wf[c], pf[b], acc[c][b]);
+      __builtin_amdgcn_s_setprio(0);
+#ifndef PS_NODMA
+      if (g == 0) ps_wait_vmcnt<ps_behind(T, RING, NWP)>();
 #endif
       if (cc == 1 && T == 4) PS_STAMP(11);
-      __builtin_amdgcn_sched_barrier(0);               // the MFMAs above stay above: their LDS reads have completed when the barrier is reached
-#ifndef PS_NOBARRIER
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-#endif
       asm volatile("" ::: "memory");
       if (cc == 1 && T == 4) PS_STAMP(12);
-      cslot = nslot;
+      if (++cslot == RING) cslot = 0;
       ++s;
-#pragma unroll
-      for (int u = 0; u < SUBS; ++u) {
-#pragma unroll
-        for (int c = 0; c < CT; ++c) wf[u][c] = wfn[u][c];
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) pq[d][u] = pn[d][u];
-      }
     };
     stage(std::integral_constant<int, 0>{});
     stage(std::integral_constant<int, 1>{});
@@ -311,54 +283,49 @@ __global__ __launch_bounds__(512) void conv3x3_pstrip_kernel(PStripArgs a, void*
     stage(std::integral_constant<int, 8>{});
     if (cc == 0) PS_STAMP(3);
   }
+  if (g == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
   PS_STAMP(4);
   // every piece (padding pieces included) has landed, every wave is done with strip and ring: LDS is free for the reduction / epilogue
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
   PS_STAMP(5);
-  if constexpr (KG == 2) {
-    // partial sums of k-group 1 -> k-group 0, through LDS in rounds of FR fragment columns (a round moves FR x 2 KiB per wave pair)
-    const int scratch = lds_end;
-    int FR = scratch / (MW * NV * CT * 1024);
-    FR = FR < 1 ? 1 : (FR > PT ? PT : FR);
+  // the two k-groups hold partial sums of the same outputs: group 0 finishes pixel fragments [0, PH), group 1 [PH, PT); each hands the
+  // other's fragments over through LDS (one float4 per lane, fragment and channel tile: conflict-free 16-byte accesses)
+  constexpr int PH = (PT + 1) / 2;
+  const int b_lo = g == 0 ? 0 : PH, b_hi = g == 0 ? PH : PT;
+  {
     float4* const sx = reinterpret_cast<float4*>(smem);
-    for (int b0 = 0; b0 < PT; b0 += FR) {
-      if (g == 1) {
 #pragma unroll
-        for (int b = 0; b < PT; ++b)
-          if (b >= b0 && b < b0 + FR) {
+    for (int b = 0; b < PT; ++b)
+      if (b < b_lo || b >= b_hi) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
-              sx[((wr * FR + (b - b0)) * CT + c) * 64 + lane] = make_float4(acc[c][b][0], acc[c][b][1], acc[c][b][2], acc[c][b][3]);
-          }
+        for (int c = 0; c < CT; ++c)
+          sx[((wr * PT + b) * CT + c) * 64 + lane] = make_float4(acc[c][b][0], acc[c][b][1], acc[c][b][2], acc[c][b][3]);
       }
-      __syncthreads();
-      if (g == 0) {
+    __syncthreads();
 #pragma unroll
-        for (int b = 0; b < PT; ++b)
-          if (b >= b0 && b < b0 + FR) {
+    for (int b = 0; b < PT; ++b)
+      if (b >= b_lo && b < b_hi) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-              const float4 v = sx[((wr * FR + (b - b0)) * CT + c) * 64 + lane];
-              acc[c][b][0] += v.x; acc[c][b][1] += v.y; acc[c][b][2] += v.z; acc[c][b][3] += v.w;
-            }
-          }
+        for (int c = 0; c < CT; ++c) {
+          const float4 v = sx[((wr * PT + b) * CT + c) * 64 + lane];
+          acc[c][b][0] += v.x; acc[c][b][1] += v.y; acc[c][b][2] += v.z; acc[c][b][3] += v.w;
+        }
       }
-      __syncthreads();
-    }
+    __syncthreads();
   }
   PS_STAMP(6);
   const ClassView cv = {};
-  tile_epilogue<BM, BN, 8, MW, NV, PT, CT, false, BNEPI>(acc, smem, m_end, m0, n0, tile_m, nullptr, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid, lane,
-                                                       wm, wn, cv, bnepi, tile_m, g == 0);
+  tile_epilogue<BM, BN, 8, MW, NV, PT, CT, false, BNEPI, KG>(acc, smem, m_end, m0, n0, tile_m, nullptr, Yv, ldy, accumulate, stat_sum, stat_sq, Kout, tid,
+                                                           lane, wm, wn, cv, bnepi, tile_m, g, b_lo, b_hi);
   PS_STAMP(7);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-struct PsVariant { int kg, mw, nv, pt; };
-constexpr PsVariant kVariants[] = {{2, 2, 2, 11}, {2, 1, 4, 11}};
-constexpr int kNumVariants = 2;
+struct PsVariant { int kg, mw, nv, pt, ct; };
+constexpr PsVariant kVariants[] = {{2, 2, 2, 11, 2}, {2, 1, 4, 11, 2}, {2, 4, 1, 6, 4}, {2, 2, 2, 6, 4}};   // 352 x 64, 176 x 128, 384 x 64, 192 x 128
+constexpr int kNumVariants = 4;
 
 struct PsPlan { int variant, bm, bn, tstride, ring, lines, wp, npieces, tiles; size_t lds; double eff; };
 
@@ -395,7 +362,7 @@ bool ps_plan_variant(const yoloconv::Gather& g, int Kout, int v, PsPlan* out) {
   PsPlan p;
   p.variant = v;
   p.bm = V.mw * V.pt * 16;
-  p.bn = V.nv * 32;
+  p.bn = V.nv * V.ct * 16;
   if (Kout % p.bn != 0) return false;
   p.wp = (g.Wo + 1 + 7) / 8 * 8;
   const int tn = Kout / p.bn;
@@ -417,7 +384,12 @@ bool ps_plan_variant(const yoloconv::Gather& g, int Kout, int v, PsPlan* out) {
     p.npieces = 1 + p.lines * (p.wp / 8);
     if (p.npieces > 8 * PS_NPW) continue;
     const size_t strip = (size_t)p.npieces * 1024, out_tile = (size_t)p.bm * (p.bn * 2 + 16);
-    auto lds = [&](int ring) { const size_t m = 2 * strip + (size_t)ring * p.bn * 128; return m > out_tile ? m : out_tile; };
+    const size_t xchg = (size_t)V.mw * V.nv * V.pt * V.ct * 1024;      // partial sums of the k-groups, exchanged after the K loop
+    auto lds = [&](int ring) {
+      size_t m = 2 * strip + (size_t)ring * p.bn * 128;
+      m = m > out_tile ? m : out_tile;
+      return m > xchg ? m : xchg;
+    };
     p.ring = lds(4) <= 160 * 1024 ? 4 : 3;
     p.lds = lds(p.ring);
     if (p.lds > 160 * 1024) continue;
@@ -431,7 +403,7 @@ bool ps_plan_variant(const yoloconv::Gather& g, int Kout, int v, PsPlan* out) {
 
 }  // namespace
 
-int g_ps_depth = 3;      // "ps_depth" tuning (development): pixel fragments read ahead of their MFMAs (1 or 3)
+int g_ps_depth = 3;      // (unused; kept for the tuning name)
 int g_pstrip = 0;         // "pstrip" tuning: -1 auto, 0 never (default while the kernel is being built up), 1 + v = force variant v where it fits
 
 // plan for a problem: 0 = the big-tile kernel is not used, else the pixels per tile (the statistics / partial rows are ceil(M / that))
@@ -439,25 +411,27 @@ int yolo_pstrip_plan(const yoloconv::Gather& g, int Kout, bool f32, PsPlanOut* o
   if (g_pstrip == 0 || !ps_eligible(g, Kout, f32)) return 0;
   PsPlan best;
   bool have = false;
-  for (int v = 0; v < kNumVariants; ++v) {
+  // measured order of preference on MI355X (tools/probes/conv_one.py): 384 x 64 (4 channel tiles per wave: fewest LDS bytes per MFMA), then
+  // 352 x 64, 192 x 128, 176 x 128
+  static const int order[kNumVariants] = {2, 0, 3, 1};
+  for (int o = 0; o < kNumVariants; ++o) {
+    const int v = order[o];
     PsPlan p;
     if (g_pstrip > 0 && v != g_pstrip - 1) continue;
     if (!ps_plan_variant(g, Kout, v, &p)) continue;
-    if (!have || p.eff > best.eff) { best = p; have = true; }
+    if (g_pstrip < 0 && (p.tiles > 256 || p.eff < 0.80)) continue;   // auto: one well-filled round of tiles only
+    if (!have) { best = p; have = true; }
   }
   if (!have) return 0;
-  if (g_pstrip < 0) {
-    // auto: deep K loops only (>= 18 K steps amortise the one prologue / epilogue a CU runs), and a single well-filled round of tiles
-    if (g.C1 < 128 || best.eff < 0.80) return 0;
-  }
+  if (g_pstrip < 0 && g.C1 < 128) return 0;            // auto: deep K loops only (>= 18 K steps per prologue / epilogue)
   if (out) { out->variant = best.variant; out->bm = best.bm; out->bn = best.bn; out->tstride = best.tstride; out->ring = best.ring; out->wp = best.wp; out->npieces = best.npieces; out->tiles = best.tiles; out->lds = best.lds; }
   return best.tstride;
 }
 
 namespace {
 
-template <int KG, int MW, int NV, int PT, int RING, bool BNEPI, int DEPTH>
-int ps_launch_d(const yoloconv::Gather& g, const PsPlanOut& pl, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st) {
+template <int KG, int MW, int NV, int PT, int CT, int RING, bool BNEPI>
+int ps_launch_e(const yoloconv::Gather& g, const PsPlanOut& pl, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st) {
   PStripArgs a;
   a.src = g.src1;
   a.N = (int)((size_t)g.M / ((size_t)g.Ho * g.Wo));
@@ -470,32 +444,26 @@ int ps_launch_d(const yoloconv::Gather& g, const PsPlanOut& pl, const void* w, v
   a.rhw = g.rhw; a.rw = g.rw; a.rh1 = 1.0f / (float)(g.Ho + 1);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pstrip_kernel<KG, MW, NV, PT, RING, BNEPI, DEPTH>),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pstrip_kernel<KG, MW, NV, PT, CT, RING, BNEPI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
     attr_set = true;
   }
   const int tn = Kout / pl.bn;
-  hipLaunchKernelGGL((conv3x3_pstrip_kernel<KG, MW, NV, PT, RING, BNEPI, DEPTH>), dim3(pl.tiles), dim3(512), pl.lds, st, a, y, ldy, accumulate, e.ssum, e.ssq, Kout, tn,
+  hipLaunchKernelGGL((conv3x3_pstrip_kernel<KG, MW, NV, PT, CT, RING, BNEPI>), dim3(pl.tiles), dim3(512), pl.lds, st, a, y, ldy, accumulate, e.ssum, e.ssq, Kout, tn,
                      e.bn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
 
-template <int KG, int MW, int NV, int PT, int RING, bool BNEPI>
-int ps_launch_e(const yoloconv::Gather& g, const PsPlanOut& pl, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st) {
-  if (g_ps_depth == 1) return ps_launch_d<KG, MW, NV, PT, RING, BNEPI, 1>(g, pl, w, y, ldy, accumulate, e, Kout, st);
-  return ps_launch_d<KG, MW, NV, PT, RING, BNEPI, 3>(g, pl, w, y, ldy, accumulate, e, Kout, st);
-}
-
-template <int KG, int MW, int NV, int PT>
+template <int KG, int MW, int NV, int PT, int CT>
 int ps_launch_v(const yoloconv::Gather& g, const PsPlanOut& pl, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st) {
   if (pl.ring == 4) {
-    if (e.bn.partial) return ps_launch_e<KG, MW, NV, PT, 4, true>(g, pl, w, y, ldy, accumulate, e, Kout, st);
-    return ps_launch_e<KG, MW, NV, PT, 4, false>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+    if (e.bn.partial) return ps_launch_e<KG, MW, NV, PT, CT, 4, true>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+    return ps_launch_e<KG, MW, NV, PT, CT, 4, false>(g, pl, w, y, ldy, accumulate, e, Kout, st);
   }
-  if (e.bn.partial) return ps_launch_e<KG, MW, NV, PT, 3, true>(g, pl, w, y, ldy, accumulate, e, Kout, st);
-  return ps_launch_e<KG, MW, NV, PT, 3, false>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+  if (e.bn.partial) return ps_launch_e<KG, MW, NV, PT, CT, 3, true>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+  return ps_launch_e<KG, MW, NV, PT, CT, 3, false>(g, pl, w, y, ldy, accumulate, e, Kout, st);
 }
 
 }  // namespace
@@ -504,8 +472,10 @@ int yolo_pstrip_launch(const yoloconv::Gather& g, const void* w, void* y, int ld
   PsPlanOut pl;
   if (!yolo_pstrip_plan(g, Kout, false, &pl)) { yolo_set_error("%s:%d: no big-tile plan", __FILE__, __LINE__); return YOLO_ERR_INVALID_ARG; }
   switch (pl.variant) {
-    case 0: return ps_launch_v<2, 2, 2, 11>(g, pl, w, y, ldy, accumulate, e, Kout, st);
-    default: return ps_launch_v<2, 1, 4, 11>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+    case 0: return ps_launch_v<2, 2, 2, 11, 2>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+    case 1: return ps_launch_v<2, 1, 4, 11, 2>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+    case 2: return ps_launch_v<2, 4, 1, 6, 4>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+    default: return ps_launch_v<2, 2, 2, 6, 4>(g, pl, w, y, ldy, accumulate, e, Kout, st);
   }
 }
 
