@@ -74,8 +74,14 @@ def test_kernel_plans_are_consistent_without_gpu():
     p = ops.conv_problem(N, H, W, 128, 128, 3, 1, 'same')
     M = N * H * W
     try:
-        # the one-tile-per-CU kernel takes this layer: 512 tiles of 338 pixels (6.5 image rows) x 64 channels, two rounds on 256 CUs
+        # the one-tile-per-CU kernel (off by default): "auto" takes layers that fill ONE round of <= 256 tiles, a forced variant any layer it fits
         ops.set_tuning('pstrip', -1)
+        assert ops.conv2d_fwd_plan(p)['family'] == 'strip'        # 52 x 52: two rounds of 338-pixel tiles -> not taken automatically
+        p26 = ops.conv_problem(N, 26, 26, 256, 256, 3, 1, 'same')
+        plan = ops.conv2d_fwd_plan(p26)
+        assert plan['family'] == 'pstrip' and plan['bm'] == 384 and plan['tile_pixels'] == 338 and plan['workgroups'] == 256
+        assert plan['lds_bytes'] <= 160 * 1024 and ops.conv2d_stat_rows(p26) == N * 26 * 26 // 338
+        ops.set_tuning('pstrip', 1)                         # forced 352 x 64 variant: 512 tiles of 338 pixels (6.5 image rows)
         plan = ops.conv2d_fwd_plan(p)
         assert plan['family'] == 'pstrip' and plan['tile_pixels'] == 338 and plan['workgroups'] == 512 and plan['lds_bytes'] <= 160 * 1024
         assert ops.conv2d_stat_rows(p) == M // 338

@@ -243,6 +243,33 @@ def test_backward_plans_agree(backbone, monkeypatch):
     assert abs(l_new[2] - l_old[2]) <= 4e-2 * abs(l_old[2]), (l_new, l_old)      # (third step: up to 2.5e-2 seen on resnet-18-v2 at equal gradients)
 
 
+def test_relu_mask_switch_alone_keeps_the_relu_derivative(monkeypatch):
+    """YOLO_RELU_MASK=0 with every other backward-plan switch left on (the fused data-gradient epilogue treats a null mask
+    as a linear unit, so a unit WITH a ReLU must not be fused when there are no sign bytes): the gradients must equal the default plan's
+    to 16-bit rounding noise, not lose the ReLU derivative"""
+    H = W = 128
+    images, labels = make_batch(4, H, W, 6, 7, seed=5)
+    from yolov3_tensorflow_amd import engine
+    grads = []
+    for mask in ('1', '0'):
+        monkeypatch.setenv('YOLO_RELU_MASK', mask)
+        model, loss, opt, grids = build('resnet-18', H, W, 4, 7, rect=-1)
+        units = [op for op in model.g.tape if isinstance(op, engine.ApplyOp)]
+        fused_relu = [op for op in units if op.producer is not None and op.relu]
+        if mask == '1':
+            assert fused_relu and all(op.mask is not None for op in fused_relu)
+        else:
+            assert not fused_relu, 'a ReLU unit without sign bytes must keep its own reduce pass'
+        model.use_hip_graph = False
+        model.stage_batch(torch.from_numpy(images), torch.from_numpy(labels))
+        model.g.training = True
+        model._fwd_bwd()
+        torch.cuda.synchronize()
+        grads.append(model.g.ps.grad.detach().float().cpu().numpy().copy())
+        del model, loss, opt
+    assert rel_l2(grads[0], grads[1]) < 2e-2, rel_l2(grads[0], grads[1])
+
+
 def test_loss_curve_graph_replay():
     """6 training steps with hipGraph replay vs the float32 oracle, at the learning rate the reference's scheduler applies in
     its first epochs (1e-5, configs.py:16-17).  Steps 1-5 take RAdam's momentum branch, step 6 the adaptive one (rho_t >= 5).

@@ -1507,12 +1507,16 @@ extern "C" int yolo_conv2d_wgrad_slabs(const yolo_conv_problem* p, const void* s
   int rc = plan_wgrad(p, src0, src1, 0, g_wgrad_target, &pl);
   if (rc) return rc;
   const size_t n = (size_t)p->Cout * (size_t)pl.g.Kg;
+  // the caller sized the slab region (and the batched summing launch's table) from yolo_conv2d_wgrad_splits at planning time: a tuning
+  // change since then (yolo_set_tuning "wgrad_target" / "wgrad_strip") must not silently sum stale slabs or overwrite a direct result
   if (pl.split_k == 1) {                              // one workgroup per tile: plain stores straight into dw, nothing to sum
+    YOLO_CHECK_ARG(slab_bytes == 0, "the plan has one split now but the caller planned slabs: re-plan after yolo_set_tuning");
     launch_wgrad(p, pl, dy, dw, (long long)n, (hipStream_t)stream);
     YOLO_LAUNCH_CHECK();
     return YOLO_OK;
   }
-  YOLO_CHECK_ARG(slabs && slab_bytes >= (size_t)pl.split_k * n * sizeof(float), "slab region too small (yolo_conv2d_wgrad_workspace_bytes)");
+  YOLO_CHECK_ARG(slabs && slab_bytes == (size_t)pl.split_k * n * sizeof(float),
+                 "slab region does not match the current split plan (yolo_conv2d_wgrad_splits; re-plan after yolo_set_tuning)");
   YOLO_CHECK_ARG((reinterpret_cast<uintptr_t>(slabs) & 15) == 0, "slabs must be 16-byte aligned");
   launch_wgrad(p, pl, dy, slabs, (long long)n, (hipStream_t)stream);
   YOLO_LAUNCH_CHECK();

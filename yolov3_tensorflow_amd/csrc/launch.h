@@ -42,6 +42,7 @@ inline void yolo_seq_pack(YoloSeqItem& it, const T& v) {
 template <typename... K, typename... A>
 inline void yolo_launch(void (*kernel)(K...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, A&&... a) {
   static_assert(sizeof...(K) == sizeof...(A), "kernel argument count");
+  static_assert(sizeof...(K) <= 64, "yolo_seq_run (capi.cpp) replays launches through a 64-entry argument pointer array");
   std::tuple<std::remove_cv_t<std::remove_reference_t<K>>...> args{static_cast<std::remove_cv_t<std::remove_reference_t<K>>>(std::forward<A>(a))...};
   void* ptrs[sizeof...(K) ? sizeof...(K) : 1];
   std::apply([&](auto&... x) { size_t i = 0; ((ptrs[i++] = (void*)&x), ...); }, args);

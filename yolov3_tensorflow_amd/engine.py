@@ -464,6 +464,8 @@ class Graph(object):
                     pa = a.y.p
                     if not (pa.R == 1 and pa.S == 1 and pa.stride == 2 and pa.pad_t == 0 and pa.pad_l == 0 and pa.Cout % 64 == 0):
                         continue
+                    if a.bn_epi is not None or a.addend is not None:
+                        continue                           # (the even-only launch takes neither a fused reduce nor an external addend)
                     if a.acc == [True]:                    # adds onto an earlier (dense) contribution: only where it has one of its own
                         a.even_only = True
                     elif a.acc == [False] and i + 1 < len(w):
@@ -915,6 +917,10 @@ class ApplyOp(object):
         and the reduce of this unit's backward pass (ops.conv2d_dgrad(bn=...)): backward() is then finalize + apply on the masked gradient"""
         w = self.out.grad_writers
         if not w or not isinstance(w[-1], ConvOp) or w[-1].y.x is not self.out or (self.m_bn is None and self.o_bn is None):
+            return
+        if self.relu and self.mask is None:
+            # YOLO_RELU_MASK=0: the epilogue could only take the ReLU derivative from a sign-byte mask (a null mask means "linear unit"
+            # to yolo_conv2d_dgrad_bn, and backward() then runs the apply with relu = 0): the unit keeps its own reduce pass
             return
         conv = w[-1]
         rows = ops.conv2d_dgrad_bn_rows(conv.y.p)

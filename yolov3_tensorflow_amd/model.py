@@ -238,11 +238,16 @@ class YOLOv3Model(object):
                         raise RuntimeError('gradient buckets cover %d of %d parameters' % (covered, g.ps.n))
                     self.optimizer.finish(self)
                     g.refresh_dgrad_async()
-                finally:
-                    if record:
-                        n = ops.seq_end()
-                        segments, self._recording = self._recording, None
-                        self._seq = (seq_id, sig, segments + [(n, None)])
+                except BaseException:
+                    if record:                      # a step that raised part-way must never be replayed: close the recording and drop it
+                        ops.seq_end()
+                        ops.seq_free(seq_id)
+                        self._recording = None
+                    raise
+                if record:                          # only a step that completed becomes the replayed launch list
+                    n = ops.seq_end()
+                    segments, self._recording = self._recording, None
+                    self._seq = (seq_id, sig, segments + [(n, None)])
                 return
             if ga is None:
                 self._fwd_bwd()
@@ -265,7 +270,7 @@ class YOLOv3Model(object):
         g = self.g
         return (self.overlap_wgrad, self.bucket_updates, self.overlap_allreduce, g.fused_bn_bwd, g.wgrad_batch, g.wgrad_cost_limit, self.world_size,
                 backend.loss_scale(), id(self.loss_obj), id(self.optimizer), int(self.loss_obj.T), g.training, g.bn_momentum,
-                torch.cuda.current_stream(self.device).cuda_stream)
+                torch.cuda.current_stream(self.device).cuda_stream, ops.tuning_epoch())
 
     def _replay(self):
         seq_id, _, segments = self._seq

@@ -40,9 +40,19 @@ def pad_channels(c):
     return p
 
 
+_tuning_epoch = 0
+
+
 def set_tuning(name, value):
-    """test / benchmark hook (yolo_set_tuning): override a kernel-selection heuristic"""
+    """test / benchmark hook (yolo_set_tuning): override a kernel-selection heuristic.  Every call advances tuning_epoch(): launch
+    decisions recorded earlier (the native step sequence of YOLOv3Model, buffer sizes planned at Graph.finalize) are stale after it"""
+    global _tuning_epoch
     check(_lib.load().yolo_set_tuning(name.encode(), int(value)), 'yolo_set_tuning')
+    _tuning_epoch += 1
+
+
+def tuning_epoch():
+    return _tuning_epoch
 
 
 def conv2d_stat_rows(p):
@@ -75,6 +85,8 @@ def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False, bn=None, addend=None, eve
     (the fan-in add with the other contribution read from its own buffer).  ``accumulate`` = 2: only the even / even positions hold a previous
     contribution (3x3 stride-2 problems); ``even_only``: a 1x1 stride-2 gradient that writes just those positions (yolo_conv2d_dgrad_even)"""
     if even_only:
+        if bn is not None or addend is not None:
+            raise ValueError('even_only data gradient takes neither a fused BatchNorm reduce (bn=) nor an external addend')
         check(_lib.load().yolo_conv2d_dgrad_even(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _stream()), 'yolo_conv2d_dgrad_even')
         return
     if bn is None:

@@ -12,7 +12,7 @@ The reference saves and restores weights through TensorFlow (yolov3/trainer.py:4
   checkpoint                      text CheckpointState: model_checkpoint_path / all_model_checkpoint_paths
 
 Table format: data blocks of prefix-compressed entries (varint32 shared, non_shared, value_len; key tail; value) with a restart point every
-16 entries, then the uint32 restart offsets and their count; every block is followed by a 5-byte trailer (compression type 0, masked CRC-32C of
+16 entries (every entry in the index block, as LevelDB / TensorFlow write it), then the uint32 restart offsets and their count; every block is followed by a 5-byte trailer (compression type 0, masked CRC-32C of
 block + type); metaindex block, index block (separator key -> BlockHandle varint64 offset, size), 48-byte footer (two handles, padding, magic
 0xdb4775248b80fb57).  Masked CRC = rotr15(crc32c) + 0xa282ead8.  Protobuf field numbers: tensor_bundle.proto, tensor_shape.proto,
 trackable_object_graph.proto.
@@ -237,12 +237,13 @@ def _short_successor(key):
 
 
 class _BlockBuilder(object):
-    def __init__(self):
+    def __init__(self, restart_interval=RESTART_INTERVAL):
         self.buf, self.restarts, self.counter, self.last = bytearray(), [0], 0, b''
+        self.restart_interval = restart_interval
 
     def add(self, key, value):
         shared = 0
-        if self.counter < RESTART_INTERVAL:
+        if self.counter < self.restart_interval:
             n = min(len(self.last), len(key))
             while shared < n and self.last[shared] == key[shared]:
                 shared += 1
@@ -273,7 +274,8 @@ def build_table(items, block_size=BLOCK_SIZE):
         out.extend(contents + trailer + struct.pack('<I', mask(crc32c(contents + trailer))))
         return handle
 
-    data, index = _BlockBuilder(), _BlockBuilder()
+    # (LevelDB / TensorFlow table builders give the INDEX block a restart interval of 1: every handle entry carries its full key)
+    data, index = _BlockBuilder(), _BlockBuilder(restart_interval=1)
     pending, last_key = None, None
     for key, value in items:
         if last_key is not None and key <= last_key:
@@ -366,7 +368,10 @@ def write_checkpoint(prefix, weights):
     d = os.path.dirname(prefix)
     if d:
         os.makedirs(d, exist_ok=True)
-    with open(prefix + '.data-00000-of-00001', 'wb') as f:
+    # both files are written under temporary names and renamed when complete: a crash mid-save leaves no torn checkpoint behind a name
+    # that the 'checkpoint' state file (updated by the caller AFTER this returns) could point to
+    tmp_data, tmp_index = prefix + '.data-00000-of-00001.tmp', prefix + '.index.tmp'
+    with open(tmp_data, 'wb') as f:
         for key in sorted(list(tensors) + [OBJECT_GRAPH_KEY]):
             if key == OBJECT_GRAPH_KEY:
                 payload, crc = _string_tensor_bytes(graph)
@@ -380,8 +385,14 @@ def write_checkpoint(prefix, weights):
                 items.append((key, encode_entry(_DT[a.dtype], a.shape, 0, offset, len(payload), mask(crc32c(a)))))
             f.write(payload)
             offset += len(payload)
-    with open(prefix + '.index', 'wb') as f:
+        f.flush()
+        os.fsync(f.fileno())
+    with open(tmp_index, 'wb') as f:
         f.write(build_table(sorted(items)))
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp_data, prefix + '.data-00000-of-00001')
+    os.replace(tmp_index, prefix + '.index')
     return keys
 
 
