@@ -121,6 +121,18 @@ def kernel_rooflines(model, steps, overlap):
 
     n_params = model.g.ps.n
     patched = {'conv2d_fwd': timed_conv(ops.conv2d_fwd), 'conv2d_dgrad': timed_conv(ops.conv2d_dgrad)}
+
+    def timed_wgrad(fn):                  # the slab pass of the weight gradient: 2 N Ho Wo Cout Cin R S FLOP as well (timed on ITS launch stream)
+        def wrapper(p, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(p, *a, **k)
+            e1.record()
+            cin = 3 if p.Cin == 8 else p.Cin
+            records.append((e0, e1, 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S, 'wgrad3x3' if is_strip(p) else 'wgrad_other'))
+        return wrapper
+    patched['conv2d_wgrad_slabs'] = timed_wgrad(ops.conv2d_wgrad_slabs)
+    patched['wgrad_reduce_batched'] = timed_bytes(ops.wgrad_reduce_batched, 'wgrad_sum')
     for name in ('bn_act_fwd', 'bn_pool_fwd'):
         patched[name] = timed_bytes(getattr(ops, name), 'bn_fwd')
     for name in ('bn_act_bwd_fused', 'bn_act_bwd_reduce', 'bn_act_bwd_apply', 'bn_pool_bwd_reduce', 'bn_pool_bwd_apply', 'stem_pool_bwd_wgrad'):
@@ -144,7 +156,7 @@ def kernel_rooflines(model, steps, overlap):
             setattr(ops, n, f)
         model.overlap_wgrad, model.g.on_bucket = saved_overlap, saved_bucket
     out = {}
-    for family in ('strip', 'strip_bn', 'other', 'other_bn', 'bn_fwd', 'bn_bwd', 'loss', 'optimizer'):
+    for family in ('strip', 'strip_bn', 'other', 'other_bn', 'wgrad3x3', 'wgrad_other', 'wgrad_sum', 'bn_fwd', 'bn_bwd', 'loss', 'optimizer'):
         rs = [r for r in records if r[3] == family]
         t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rs)
         work = sum(r[2] for r in rs)
@@ -169,6 +181,41 @@ def strip_hbm_traffic():
         except (KeyError, ValueError, OSError):
             continue
     return None, 'no PMC summary committed'
+
+
+def parity_statement(dtype):
+    """which build holds north_star's 1e-3 on the loss curve: the committed 20-step configs[0] curves against the float32 oracle
+    (tools/loss_curve.py on the GPU box; newest profiles/r*_loss_curve_config1*.json).  The headline run itself is synthetic data."""
+    import glob
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+    out = {'tolerance': 1e-3, 'reference': 'float32 CPU oracle (restatement of the reference; parity with TensorFlow itself is unpinned: TF not installable here)',
+           'workload': 'BASELINE.json configs[0]: ResNet18 320x320, the reference\'s 20 sample images, batch 2, 20 steps', 'headline_dtype': dtype}
+    for key, pat in (('bf16', 'r*_loss_curve_config1.json'), ('fp16', 'r*_loss_curve_config1_fp16.json')):
+        files = sorted(glob.glob(os.path.join(here, pat)))
+        if not files:
+            continue
+        try:
+            d = json.load(open(files[-1]))['float32_oracle']
+            out[key] = {'max': round(d['max'], 6), 'median': round(d['median'], 6), 'within_1e-3': '%d/%d' % (d['steps_within_1e-3'], len(d['relative_deviation'])),
+                        'source': 'profiles/' + os.path.basename(files[-1])}
+        except (KeyError, ValueError, OSError):
+            continue
+    out['holds_1e-3_on_every_step'] = [k for k in ('bf16', 'fp16') if k in out and out[k]['within_1e-3'].split('/')[0] == out[k]['within_1e-3'].split('/')[1]]
+    return out
+
+
+def rccl_statement(model, world, device):
+    """what the process group looked like to this run (multi-GPU records must describe themselves): backend, world size seen by the group,
+    the gradient buckets' bytes and the communication time that was NOT hidden behind the backward pass"""
+    import torch.distributed as dist
+    g = model.g
+    bytes_per = [int((hi - lo) * 4) for (_, lo, hi) in g.buckets]
+    exposed = model.measure_exposed_comm_ms() if hasattr(model, 'measure_exposed_comm_ms') else None
+    seen = [None] * world
+    dist.all_gather_object(seen, {'rank': dist.get_rank(), 'device': str(device), 'name': torch.cuda.get_device_name(device)})
+    return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks': seen, 'bucket_bytes_in_completion_order': bytes_per,
+            'gradient_dtype': 'float32', 'exposed_comm_ms_per_step': exposed,
+            'overlap': 'each bucket is all-reduced on a communication stream as soon as its last gradient is enqueued; its RAdam + L2 launch follows there'}
 
 
 def _cpu_model():
@@ -367,6 +414,20 @@ def main():
                                         'strip_launches_per_step': alone['strip_bn']['launches_per_step'],
                                         'igemm_achieved': round(alone['other_bn']['rate'] / 1e12, 2),
                                         'igemm_launches_per_step': alone['other_bn']['launches_per_step']},
+                           'wgrad': {'kernel': 'wgrad3x3_strip_kernel (3x3 stride-1 layers) / igemm_wgrad_kernel (the rest) on the weight-gradient stream; '
+                                               'slab_sum = wgrad_reduce_batched_kernel (one launch per gradient bucket, HBM-bound)',
+                                     'strip_achieved': round(alone['wgrad3x3']['rate'] / 1e12, 2),
+                                     'strip_frac': round(alone['wgrad3x3']['rate'] / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                     'strip_in_step_achieved': round(instep['wgrad3x3']['rate'] / 1e12, 2),
+                                     'strip_launches_per_step': alone['wgrad3x3']['launches_per_step'],
+                                     'strip_ms_per_step': round(alone['wgrad3x3']['ms_per_step'], 4),
+                                     'other_achieved': round(alone['wgrad_other']['rate'] / 1e12, 2),
+                                     'other_launches_per_step': alone['wgrad_other']['launches_per_step'],
+                                     'other_ms_per_step': round(alone['wgrad_other']['ms_per_step'], 4),
+                                     'family_ms_per_step': round(alone['wgrad3x3']['ms_per_step'] + alone['wgrad_other']['ms_per_step'], 4),
+                                     'family_in_step_ms_per_step': round(instep['wgrad3x3']['ms_per_step'] + instep['wgrad_other']['ms_per_step'], 4),
+                                     'slab_sum_ms_per_step': round(alone['wgrad_sum']['ms_per_step'], 4),
+                                     'slab_sum_launches_per_step': alone['wgrad_sum']['launches_per_step']},
                            'other_conv': {'kernel': 'igemm_fwd_kernel (stem, stride-2, 1x1, fused-concat launches)',
                                           'achieved': round(alone['other']['rate'] / 1e12, 2), 'in_step_achieved': round(instep['other']['rate'] / 1e12, 2),
                                           'avg_launch_ms': round(alone['other']['avg_launch_ms'], 5),
@@ -383,6 +444,10 @@ def main():
                                'in_step_achieved': round(b['rate'] / 1e9, 1), 'ms_per_step': round(a['ms_per_step'], 4),
                                'in_step_ms_per_step': round(b['ms_per_step'], 4), 'launches_per_step': a['launches_per_step'],
                                'MB_per_step': round(a['work_per_step'] / 1e6, 1)}
+    if rank == 0:
+        out['parity'] = parity_statement(args.dtype)
+    if world > 1:
+        out['rccl'] = rccl_statement(model, world, device)       # collective (a tiny all-gather of the per-rank view): every rank calls it
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(H, W, args.classes)
     if rank == 0:

@@ -126,3 +126,59 @@ def test_per_rank_batch_is_the_global_batch_divided():
     assert parallel.per_rank_batch(256, 8) == 32 and parallel.per_rank_batch(3, 1) == 3
     with pytest.raises(ValueError):
         parallel.per_rank_batch(3, 2)
+
+
+# ---- gradient buckets (engine.plan_buckets): stage marks, and the finer cut a data-parallel run uses ----
+def _resnet18_like_layout():
+    """(convs, n) of a ResNet18-YOLOv3-shaped parameter buffer: one entry per block of layers, creation order (backbone, then heads)"""
+    blocks = [(1728, 208), (4 * 36864 + 4096, 104), (73728 + 147456 * 3 + 8192, 52), (294912 + 589824 * 3 + 32768, 26),
+              (1179648 + 2359296 + 131072, 13), (2 * 2359296, 13), (2359296 + 130560, 13), (1179648 + 131072 + 1179648 + 130560, 26),
+              (32768 + 32768 + 294912 + 65280, 52)]
+    convs, off = [], 0
+    for i, (params, h) in enumerate(blocks):
+        convs.append((len(blocks) - 1 - i, off, h))
+        off += params
+    return convs, off
+
+
+def test_bucket_plan_stage_marks_and_size_cuts():
+    from yolov3_tensorflow_amd.engine import plan_buckets
+    convs, n = _resnet18_like_layout()
+    stage = plan_buckets(convs, 416, n, None)
+    assert [b[1:] for b in stage] == [(2774720, None), (153280, 2774720)]          # [first stride-32 conv, n), [first stride-8 conv, that)
+    fine = plan_buckets(convs, 416, n, 4 << 20)                                    # 16 MB of float32 gradient
+    los = [lo for _, lo, _ in fine]
+    assert los == sorted(los, reverse=True) and los[-1] == 153280 and 2774720 in los and len(fine) >= 4
+    assert fine[0][2] is None and all(fine[i + 1][2] == fine[i][1] for i in range(len(fine) - 1))     # a partition of [tail, n)
+    cuts = [c for c, _, _ in fine]
+    assert cuts == sorted(cuts)                                                    # completion order = backward launch order
+    sizes = [(n if hi is None else hi) - lo for _, lo, hi in fine]
+    assert max(sizes) < 0.5 * n                                                    # no single collective carries most of the gradient any more
+    assert plan_buckets(convs, 416, n, 1 << 40) == stage                           # a huge target changes nothing
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank))
+    from yolov3_tensorflow_amd.engine import plan_buckets
+    dist.init_process_group('gloo')
+    convs, n = _resnet18_like_layout()
+    buckets = plan_buckets(convs, 416, n, 4 << 20)
+    ranges = [(lo, n if hi is None else hi) for _, lo, hi in buckets] + [(0, buckets[-1][1])]       # + the tail range after the backward pass
+    gen = torch.Generator().manual_seed(11 + rank)
+    grad = torch.randn(n // 64, generator=gen).repeat_interleave(64)              # (cheap to generate, still rank-specific everywhere)
+    whole = grad.clone()
+    for lo, hi in ranges:                                                          # bucket by bucket, in completion order, as the step does
+        dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM)
+    dist.all_reduce(whole, op=dist.ReduceOp.SUM)
+    out[rank] = (bool(torch.equal(grad, whole)), sum(hi - lo for lo, hi in ranges) == n, len(ranges))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_one_allreduce_world2():
+    """the finer buckets of a data-parallel run partition the flat gradient: all-reducing them one by one (gloo, two ranks) gives the sum
+    one collective over the whole buffer gives, bit for bit"""
+    world, port = 2, 29751
+    out = mp.Manager().dict()
+    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == out[1] and out[0][0] and out[0][1] and out[0][2] >= 5

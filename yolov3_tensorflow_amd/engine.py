@@ -479,19 +479,17 @@ class Graph(object):
         #   [first stride-8 conv, that) the stride-8 / stride-16 stages
         #   [0, first stride-8 conv)    stem + stride-4 stage (~1 % of the parameters): the only bucket whose all-reduce is exposed
         # self.buckets = [(index in the backward launch list after which the bucket is complete, lo, hi), ...] in completion order
+        # Data parallel (WORLD_SIZE > 1, or YOLO_BUCKET_MB set): a stage bucket larger than YOLO_BUCKET_MB (default 16 MB of float32
+        # gradient) is cut further at convolution boundaries, so that the first all-reduce starts a few layers into the backward pass
+        # instead of after module512 + all three heads (~47 MB in one collective).
         H = self.input_val.shape[1]
-        marks = []
-        for div in (32, 8):
-            for i, op in enumerate(self.tape):
-                if isinstance(op, ConvOp) and op.y.shape[1] == H // div and (not marks or op.y.wp.offset < marks[-1][1]):
-                    marks.append((len(self.tape) - 1 - i, op.y.wp.offset))
-                    break
-        self.buckets = []
-        hi = None
-        for cut, lo in marks:
-            if lo > 0:
-                self.buckets.append((cut, lo, hi))            # hi = None: up to ps.n (known after allocation)
-                hi = lo
+        convs = [(len(self.tape) - 1 - i, op.y.wp.offset, op.y.shape[1]) for i, op in enumerate(self.tape) if isinstance(op, ConvOp)]
+        mb = os.environ.get('YOLO_BUCKET_MB')
+        if mb is None and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            mb = '16'
+        target = int(float(mb) * (1 << 20) / 4) if mb else None
+        self.buckets = plan_buckets(convs, H, self.ps.n, target)
+        hi = self.buckets[-1][1] if self.buckets else None
         self.bucket_tail = hi                                  # [0, bucket_tail) remains after the backward pass (None: everything)
         if self.buckets:
             self.bucket_cut, self.bucket_offset = self.buckets[0][0], self.buckets[0][1]     # (kept: first bucket, for introspection / tests)
@@ -659,6 +657,37 @@ class Graph(object):
 
 
 # ==================================================================================================================== ops
+def plan_buckets(convs, H, n=None, target=None):
+    """gradient buckets in completion order.  ``convs`` = [(index in the backward launch list after which this convolution's weight gradient
+    (and everything created after it) is complete, offset of its kernel in the flat parameter buffer, output height)] in creation order;
+    parameters are laid out in creation order and the backward pass runs in reverse, so the range [offset, n) is complete at that index.
+    Stage marks: the first convolution at stride 32 and the first at stride 8 (the range [0, first stride-8 convolution) is the tail the
+    caller handles after the backward pass).  ``target`` (elements, needs ``n`` = all parameters): additionally cut at a convolution
+    whenever the bucket that ends there has reached that many parameters.  Returns [(cut index, lo, hi or None for "up to n")]."""
+    marks = []
+    for div in (32, 8):
+        for cut, off, h in convs:
+            if h == H // div and (not marks or off < marks[-1][1]):
+                marks.append((cut, off))
+                break
+    cuts = {off: cut for cut, off in marks if off > 0}
+    if target and n is not None and cuts:
+        stop, hi = min(cuts), n                               # nothing below the last stage mark is cut further (the tail stays one range)
+        for cut, off, _ in sorted(convs, key=lambda c: -c[1]):                # backward order: descending offsets
+            if off < stop:
+                break
+            if off in cuts:
+                hi = off
+            elif hi - off >= target:
+                cuts[off] = cut
+                hi = off
+    out, hi = [], None
+    for off in sorted(cuts, reverse=True):
+        out.append((cuts[off], off, hi))
+        hi = off
+    return out
+
+
 class ConvOp(object):
     def __init__(self, g, y):
         self.g, self.y = g, y

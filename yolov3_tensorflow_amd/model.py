@@ -229,10 +229,18 @@ class YOLOv3Model(object):
                         g.on_bucket = None
                         g.tail_on_main = False
                     main = torch.cuda.current_stream(self.device)
+                    probe = getattr(self, '_comm_probe', None)
+                    if probe is not None:                            # measure_exposed_comm_ms: main-stream time spent waiting in the joins
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record(main)
                     if self._comm_stream is not None and dp:
                         g.stream_wait(main, self._comm_stream)
                     if g.wgrad_stream is not None and not tail:     # (tail: the main stream joined the side stream before the last range)
                         g.stream_wait(main, g.wgrad_stream)
+                    if probe is not None:
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record(main)
+                        probe.append((e0, e1))
                     covered = sum(hi - lo for lo, hi in self._step_ranges)
                     if covered != g.ps.n:
                         raise RuntimeError('gradient buckets cover %d of %d parameters' % (covered, g.ps.n))
@@ -262,6 +270,24 @@ class YOLOv3Model(object):
                 self._update()
             else:
                 gb.replay()
+
+    def measure_exposed_comm_ms(self, steps=3):
+        """milliseconds per step the main stream waits, after its own last kernel, for the communication (and weight-gradient) stream:
+        the part of the gradient exchange + per-bucket updates that the backward pass did NOT hide.  Runs ``steps`` eagerly enqueued
+        steps (collective on every rank)."""
+        saved = self.native_sequencer
+        self.native_sequencer = False
+        self._drop_sequence()
+        self._comm_probe = []
+        try:
+            for _ in range(steps + 1):
+                self.run_step()
+            torch.cuda.synchronize(self.device)
+            spans = [a.elapsed_time(b) for a, b in self._comm_probe[1:]]
+        finally:
+            self._comm_probe = None
+            self.native_sequencer = saved
+        return round(sum(spans) / max(len(spans), 1), 4) if spans else None
 
     # ---------------------------------------------------------------------------------------------- native launch sequencer
     def _step_signature(self):
