@@ -209,7 +209,7 @@ def rccl_statement(model, world, device):
     the gradient buckets' bytes and the communication time that was NOT hidden behind the backward pass"""
     import torch.distributed as dist
     g = model.g
-    bytes_per = [int((hi - lo) * 4) for (_, lo, hi) in g.buckets]
+    bytes_per = [int((hi - lo) * 4) for (lo, hi) in g.bucket_ranges]      # completion order; the last one is the tail after the backward pass
     exposed = model.measure_exposed_comm_ms() if hasattr(model, 'measure_exposed_comm_ms') else None
     seen = [None] * world
     dist.all_gather_object(seen, {'rank': dist.get_rank(), 'device': str(device), 'name': torch.cuda.get_device_name(device)})

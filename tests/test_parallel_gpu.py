@@ -56,7 +56,10 @@ opt.launch_range = spy
 model.run_step()
 opt.launch_range = orig_range
 torch.cuda.synchronize()
-assert len(ranges) == 3 and [r[2] for r in ranges] == [True, False, False] and sum(hi - lo for lo, hi, _ in ranges) == model.g.ps.n, ranges
+# (world size 2: the stage buckets are cut further at 16 MB -- module512 + heads no longer travel as one ~47 MB collective)
+assert len(ranges) >= 4 and [r[2] for r in ranges] == [True] + [False] * (len(ranges) - 1), ranges
+assert sum(hi - lo for lo, hi, _ in ranges) == model.g.ps.n and max(hi - lo for lo, hi, _ in ranges) < 0.5 * model.g.ps.n, ranges
+assert all(ranges[i + 1][1] == ranges[i][0] for i in range(len(ranges) - 1)) and ranges[-1][0] == 0, ranges
 err = float((captured - g_sum).abs().max()) / max(float(g_sum.abs().max()), 1e-12)
 for _ in range(2):
     model.run_step()

@@ -118,8 +118,13 @@ def test_forward_loss_grads_and_step(backbone, rect, compute_dtype, focal):
     for hg, ho in zip(heads_gpu, res['bf16'][0]):
         assert rel_l2(hg.numpy(), ho.detach().numpy()) < 3e-2
     # loss: 1e-3 relative vs the bf16-emulating oracle (north_star's 1e-3), 2e-2 vs the float32 oracle (precision choice)
-    # (bf16 + focal, a case beyond BASELINE.json's configs: 1.1e-3 measured -- the focal factor p^gamma steepens the loss around the few
-    #  confident background cells, where one bf16 rounding flip upstream moves the sum; bound 2e-3 there)
+    # (bf16 + focal, a case beyond BASELINE.json's configs: 1.0-1.1e-3 measured, box to box.  Located with tools/focal_gap.py
+    #  (profiles/r03_focal_gap.json): the loss KERNEL agrees with the oracle on the GPU's own logits to 1e-7; no ground truth changes its
+    #  responsible (head, cell, anchor); the whole gap (+0.106 of 93.07) is the squared-log WH term at the 11 responsible predictions, whose
+    #  raw wh logits differ by the ~2 % relative L2 that summation-order noise reaches after ~20 BatchNorm layers (both sides round at the
+    #  same storage points, the convolution sums run in different orders) -- 42 % of it at ONE prediction: image 2, head /32, cell (2, 1),
+    #  anchor 1, t_w = -0.1319 here vs -0.1402 emulated.  The focal factor is not involved: it shrinks the no-object term (22.6 of the
+    #  93) and with it the denominator of the relative gap; the same absolute noise is 5e-4 of the 200+ non-focal loss.  Bound 2e-3.)
     tol_emu = 2e-3 if (focal and not half) else 1e-3
     assert abs(loss_gpu - res['bf16'][1]) <= tol_emu * abs(res['bf16'][1]), (loss_gpu, res['bf16'][1], res['f32'][1])
     assert abs(loss_gpu - res['f32'][1]) <= 2e-2 * abs(res['f32'][1]), (loss_gpu, res['f32'][1])

@@ -1,9 +1,5 @@
 set -o pipefail
 export TMPDIR=/tmp
-for i in 1 2; do
-  for t in "pstrip=0" "pstrip=-1"; do
-    echo "== $t" >> gpurun_out/r3e_bench.txt
-    YOLO_TUNE=$t timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-roofline 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" >> gpurun_out/r3e_bench.txt
-  done
-done
-cat gpurun_out/r3e_bench.txt
+timeout -k 10 300 python tools/focal_gap.py > gpurun_out/r3f_focal_gap.json 2> gpurun_out/r3f_focal_gap.err; echo "focal rc=$?"
+YOLO_BENCH_SHARE_GPU=1 YOLO_DIST_BACKEND=gloo timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 4 --warmup 2 --no-roofline > gpurun_out/r3f_bench2.log 2>&1; echo "bench2 rc=$?"; grep '^{' gpurun_out/r3f_bench2.log | tail -1 > gpurun_out/r3f_bench2.json
+python -m pytest tests/test_parallel_gpu.py -x -q > gpurun_out/r3f_tests2.log 2>&1; echo "tests2 rc=$?"; tail -3 gpurun_out/r3f_tests2.log
