@@ -163,3 +163,46 @@ def test_data_parallel_ranks_read_disjoint_slices_of_the_single_process_batches(
             np.testing.assert_array_equal(a, b)
     with pytest.raises(ValueError):
         next(FileUtil.host_batches(label, str(tmp_path), (64, 64), 2, rank=2, world=2))
+
+
+def test_letterbox_matches_the_references_own_frames():
+    """SURVEY 8f-1 geometry, pinned against the reference itself: dataset/test_result/*.jpg are the reference's OWN 480 x 384 letterboxed frames
+    of its 20 sample images (yolov3_post_process.py:199-204 writes the network input of file_util.py:47-59 with the boxes drawn on it;
+    fixture tests/golden/letterbox_frames.npz = those files' bytes, made by tests/golden/make_letterbox_golden.py).  oracle.dataset.letterbox
+    of the same sample image must match each frame within JPEG noise -- scale, offset and nearest-neighbour sampling -- and EVERY one-pixel
+    shift must be strictly worse.  The drawn box lines / labels are masked by the per-pixel outlier rule (|difference| > 48 grey levels)."""
+    import io
+    from PIL import Image
+    from oracle import dataset as ods
+    from yolov3_tensorflow_amd.dataset.file_util import FileUtil
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    d = np.load(os.path.join(here, 'letterbox_frames.npz'))
+    names = [str(n) for n in d['names']]
+    assert len(names) == 20
+    H, W = 384, 480                                          # configs.py:36 input_image_size
+    for k, name in enumerate(names):
+        ref = np.asarray(Image.open(io.BytesIO(d['jpeg_bytes'][d['offsets'][k]:d['offsets'][k + 1]].tobytes())).convert('RGB')).astype(np.int32)
+        assert ref.shape == (H, W, 3)
+        src = FileUtil.read_image(os.path.join(here, 'test_sample', 'images', name))
+        box = ods.letterbox(src, (H, W, 3)).astype(np.int32)
+        nh, nw, top, left = ods.letterbox_geometry(src.shape[0], src.shape[1], H, W)
+
+        def score(dy, dx):
+            a = box[top + 2:top + nh - 2, left + 2:left + nw - 2]
+            b = ref[top + 2 + dy:top + nh - 2 + dy, left + 2 + dx:left + nw - 2 + dx]
+            diff = np.abs(a - b).max(-1)
+            keep = diff <= 48
+            return float(diff[keep].mean()), float(keep.mean())
+
+        aligned, inliers = score(0, 0)
+        assert aligned <= 8.0 and inliers >= 0.95, (name, aligned, inliers)          # measured 3.3 .. 5.4 grey levels, >= 97 % inliers
+        for dy, dx in ((0, 1), (0, -1), (1, 0), (-1, 0), (1, 1), (-1, -1), (1, -1), (-1, 1)):
+            shifted = score(dy, dx)[0]
+            assert shifted >= 1.4 * aligned, (name, (dy, dx), shifted, aligned)        # measured >= 1.9 x
+        # the zero bars sit where the geometry says (JPEG ringing only), the first content row / column next to them does not
+        # (99th percentile: a drawn box label may reach into a bar)
+        for bar in (ref[:max(top - 2, 0)], ref[top + nh + 2:], ref[:, :max(left - 2, 0)], ref[:, left + nw + 2:]):
+            if bar.size:
+                assert np.percentile(bar, 99) <= 24, (name, bar.shape)
+        inside = ref[top + 2:top + nh - 2, left + 2:left + nw - 2]
+        assert inside.mean() > 24, name                       # (and the content is not itself dark)
