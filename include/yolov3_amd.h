@@ -174,6 +174,28 @@ int yolo_bn_finalize_act_fwd(const float* psum, const float* psq, int P, int64_t
                              const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* scale,
                              float* shift, float* mean, float* rstd, const void* y, const void* res, void* out, uint8_t* relu_mask,
                              int64_t M, int relu, void* stream);
+/* Exact cross-workgroup accumulators: BatchNorm statistics WITHOUT partial rows and without a finalize launch.  A block holds, for Q
+ * quantities of C channels, 16 buckets of two int64 limbs each (value * 2^20 = hi + lo * 2^-40) plus a flag word; kernels add their
+ * workgroup sums with 64-bit integer atomics, which are associative: the totals are bit-reproducible whatever the arrival order, unlike
+ * float atomics.  yolo_acc_words(Q, C) = size of a block in 8-byte words; the caller zeroes all blocks once per step (yolo_zero_words)
+ * before the first kernel that adds to them.  Replaces, like the functions above, the statistics of tf.keras BatchNormalization
+ * (backbone/basic_backbone.py:68-78) and their TF autodiff. */
+int64_t yolo_acc_words(int Q, int C);
+int yolo_zero_words(int64_t* words, int64_t n, void* stream);
+/* yolo_conv2d_fwd (16-bit output, no bias, not the RGB stem) adding sum / sum of squares of the stored outputs to stat_acc (Q = 2, C = Cout) */
+int yolo_conv2d_fwd_acc(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd, void* y, int64_t* stat_acc, void* stream);
+/* yolo_bn_finalize_act_fwd reading the statistics from such a block: any number of pixel tiles upstream */
+int yolo_bn_finalize_act_fwd_acc(const int64_t* stat_acc, int C, float count, const float* gamma, const float* beta, float eps, float momentum,
+                                 float* moving_mean, float* moving_var, float* scale, float* shift, float* mean, float* rstd, const void* y,
+                                 const void* res, void* out, uint8_t* relu_mask, int64_t M, int relu, void* stream);
+/* yolo_conv2d_dgrad_bn with the tile sums added to an accumulator block (Q = 3, C = Cin) when partial is NULL, and yolo_bn_bwd_finalize_apply
+ * reading such a block */
+int yolo_conv2d_dgrad_bn_acc(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend,
+                             const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2, const float* mean2,
+                             const float* rstd2, float* partial, int64_t* acc, void* stream);
+int yolo_bn_bwd_finalize_apply_acc(const int64_t* acc, int C, float count, float* dgamma, float* dbeta, float* k1, float* k2, const void* g,
+                                   const void* y, const float* a1, const float* mean, const float* rstd, void* dy, int acc_dy, void* dres,
+                                   int acc_dres, int64_t M, void* stream);
 /* The same finalize for up to 4 BatchNorms over consecutive channel groups of ONE tensor (MixNet's grouped BN: shared statistics work
  * vectors, separate gamma / beta / moving statistics / gradient slots): split[0..ngroups] (host) = group boundaries, the pointer arrays
  * (host arrays of device pointers) have ngroups entries.  One launch instead of one per group. */

@@ -72,7 +72,7 @@ def mocked_kernels(monkeypatch):
         fn = getattr(ops, name)
         if callable(fn) and getattr(fn, '__module__', None) == ops.__name__ and name not in (
                 'same_pad', 'conv_problem', 'mix_problem', 'pad_channels', 'make_loss_config', 'conv2d_stat_rows', 'reduce_rows', 'radam_l2_blocks',
-                'loss_workspace_bytes', 'check', '_p', '_stream', 'conv2d_wgrad_workspace_bytes', 'conv2d_wgrad_splits', 'conv2d_dgrad_bn_rows', 'conv2d_dgrad_classed', 'stem_pool_bwd_slabs', 'reduce_blocks', 'bn_bwd_fused_workspace_floats', 'bn_bwd_fused_sync_words', 'dwconv_mix_wgrad_workspace_bytes'):
+                'loss_workspace_bytes', 'check', '_p', '_stream', 'conv2d_wgrad_workspace_bytes', 'conv2d_wgrad_splits', 'conv2d_dgrad_bn_rows', 'conv2d_dgrad_classed', 'stem_pool_bwd_slabs', 'reduce_blocks', 'bn_bwd_fused_workspace_floats', 'bn_bwd_fused_sync_words', 'dwconv_mix_wgrad_workspace_bytes', 'conv2d_fwd_plan', 'acc_words', 'tuning_epoch', 'set_tuning'):
             monkeypatch.setattr(ops, name, (lambda n: (lambda *a, **k: calls.append(n)))(name))
     monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
     monkeypatch.setattr(torch.cuda, 'current_device', lambda: 0)
@@ -118,10 +118,15 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
     assert c['loss_fwd_bwd'] == 1 and c['radam_l2_step'] == 1 and c['radam_schedule'] == 1 and c['upcat_split_bwd'] == 2
     from yolov3_tensorflow_amd import engine
     # (small maps -- every map of this 96 x 96 input -- run finalize + apply as ONE launch where the unit has a single plain BatchNorm)
-    assert c['bn_finalize'] + c['bn_finalize_act_fwd'] + 4 * c['bn_finalize_grouped'] == n_bn      # MixNet: one grouped launch per 4 group BatchNorms
-    assert c['bn_finalize_act_fwd'] + c['bn_act_fwd'] == len([op for op in m.g.tape if isinstance(op, engine.ApplyOp)])
-    assert c['bn_finalize_act_fwd'] > 0 and c['bn_bwd_finalize_apply'] > 0
-    assert c['bn_bwd_finalize_apply'] + c['bn_act_bwd_apply'] <= c['bn_finalize_act_fwd'] + c['bn_act_fwd']
+    # (every unit with a single plain BatchNorm over a convolution runs finalize + apply as ONE launch fed by an exact accumulator block:
+    #  no statistics rows, no finalize launch, at any map size; the blocks of a step are zeroed by one launch)
+    merged_f = c['bn_finalize_act_fwd'] + c['bn_finalize_act_fwd_acc']
+    merged_b = c['bn_bwd_finalize_apply'] + c['bn_bwd_finalize_apply_acc']
+    assert c['bn_finalize'] + merged_f + 4 * c['bn_finalize_grouped'] == n_bn      # MixNet: one grouped launch per 4 group BatchNorms
+    assert merged_f + c['bn_act_fwd'] == len([op for op in m.g.tape if isinstance(op, engine.ApplyOp)])
+    assert c['bn_finalize_act_fwd_acc'] > 0 and c['bn_bwd_finalize_apply_acc'] > 0 and c['zero_words'] == 1
+    assert c['bn_finalize_act_fwd'] == 0 and c['bn_bwd_finalize_apply'] == 0        # (what the row-fed merged launch served, the accumulators serve too)
+    assert merged_b + c['bn_act_bwd_apply'] <= merged_f + c['bn_act_fwd']
     if n_dw:
         assert c['dwconv_mix_fwd'] == 8 and c['dwconv_mix_dgrad'] == 8 and c['dwconv_mix_wgrad'] == 8
     # backward plan of the BatchNorm units: the data gradient that writes a unit's output gradient LAST carries its reduce (every unit whose
@@ -137,7 +142,11 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
         last_is_conv = bool(w) and isinstance(w[-1], engine.ConvOp) and w[-1].y.x is op.out
         assert (op.producer is not None) == (last_is_conv and (op.m_bn is not None or op.o_bn is not None))
         if op.producer is not None:
-            assert op.producer.bn_epi['partial'] is op.fpartial and op.fpartial.shape[1:] == (3, op.C) and float(op.fpartial.abs().sum()) == 0.0
+            epi = op.producer.bn_epi
+            if getattr(op, 'acc_b', None) is not None:        # tile sums into the unit's accumulator block (3 quantities x Cin) instead of rows
+                assert epi['partial'] is None and epi['acc'] is op.acc_b and op.acc_b.numel() == 16 * 3 * 2 * op.C + 2
+            else:
+                assert epi['partial'] is op.fpartial and op.fpartial.shape[1:] == (3, op.C) and float(op.fpartial.abs().sum()) == 0.0
     # (the mocked single-launch kernel 'declines', so every unit without a producer also takes the three-kernel path here)
     assert c['bn_act_bwd_reduce'] == len([op for op in units if op.producer is None and (op.m_bn is not None or op.o_bn is not None)])
     n_alias = sum(1 for op in units if op.skip_dres)

@@ -1251,3 +1251,117 @@ def test_fp16_build_strip_and_wgrad_strip(dev, fp16):
     test_bn_act_fwd_bwd(dev, 'res_bn')
     test_bn_pool_relu_fwd_bwd(dev)
     test_mixconv_fwd_dgrad_wgrad(dev, 128, 2, 11, 9)
+
+
+def _acc_totals(acc, Q, C):
+    """decode an exact accumulator block (common.h yolo_acc_*): [16 buckets][Q][2 limbs][C] int64 + flag -> (Q, C) float64 totals, flag"""
+    a = acc[:16 * Q * 2 * C].reshape(16, Q, 2, C).sum(0).cpu()
+    return a[:, 0].double() * 2.0 ** -20 + a[:, 1].double() * 2.0 ** -60, int(acc[16 * Q * 2 * C].item())
+
+
+@pytest.mark.parametrize('case', [(4, 52, 52, 128, 64, True), (3, 104, 104, 64, 64, False), (6, 13, 13, 256, 512, True), (5, 26, 30, 64, 128, False)])
+def test_batchnorm_statistics_through_exact_accumulators(dev, case):
+    """conv2d_fwd(stat_acc=) + bn_finalize_act_fwd_acc against the statistics-rows path (conv2d_fwd rows + bn_finalize_act_fwd): the block's
+    totals ARE the sums of the rows (same per-workgroup float32 sums, added exactly), so scale / shift / mean / rstd agree to float32 rounding and
+    the activations are the same bits; the backward twin (conv2d_dgrad(bn=dict(acc=...)) + bn_bwd_finalize_apply_acc) likewise.  Integer
+    atomics are associative: two launches leave bit-identical blocks."""
+    from yolov3_tensorflow_amd import ops
+    N, H, W, Cin, Cout, relu = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    M = N * H * W
+    p = ops.conv_problem(N, H, W, Cin, Cout, 3, 1, 'same')
+    x = bf(torch.randn(N, H, W, Cin, generator=g)).to(dev)
+    w = bf(torch.randn(Cout, 3, 3, Cin, generator=g) / math.sqrt(9 * Cin)).to(dev)
+    res = bf(torch.randn(N, H, W, Cout, generator=g)).to(dev)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    # rows path
+    rows = ops.conv2d_stat_rows(p)
+    ssum, ssq = torch.zeros(rows, Cout, device=dev), torch.zeros(rows, Cout, device=dev)
+    y0 = torch.empty(N, H, W, Cout, dtype=ACT(), device=dev)
+    ops.conv2d_fwd(p, x, w, y0, stat_sum=ssum, stat_sq=ssq)
+    # accumulator path
+    acc = torch.zeros(ops.acc_words(2, Cout), dtype=torch.int64, device=dev)
+    y1 = torch.empty_like(y0)
+    ops.conv2d_fwd(p, x, w, y1, stat_acc=acc)
+    torch.cuda.synchronize()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    tot, flag = _acc_totals(acc, 2, Cout)
+    assert flag == 0
+    torch.testing.assert_close(tot[0], ssum.double().sum(0).cpu(), rtol=1e-12, atol=1e-9)
+    torch.testing.assert_close(tot[1], ssq.double().sum(0).cpu(), rtol=1e-12, atol=1e-9)
+    acc2 = torch.zeros_like(acc)
+    ops.conv2d_fwd(p, x, w, y1, stat_acc=acc2)
+    torch.cuda.synchronize()
+    assert torch.equal(acc, acc2), 'integer accumulation must not depend on the arrival order'
+
+    def state():
+        return [torch.zeros(Cout, device=dev) for _ in range(4)] + [torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)]
+    outs = []
+    for use_acc in (False, True):
+        scale, shift, mean, rstd, mm, mv = state()
+        out = torch.empty_like(y0)
+        mask = torch.zeros(M * Cout // 8, dtype=torch.uint8, device=dev) if relu else None
+        if use_acc:
+            ops.bn_finalize_act_fwd_acc(acc, Cout, M, gamma, beta, 1e-5, 0.9, mm, mv, scale, shift, mean, rstd, y0, out, M, relu, res=res, mask=mask)
+        else:
+            if rows > 4096:
+                pytest.skip('rows path of the merged launch is not meant for this many rows')
+            ops.bn_finalize_act_fwd(ssum.view(-1), ssq.view(-1), rows, Cout, Cout, M, gamma, beta, 1e-5, 0.9, mm, mv, scale, shift, mean, rstd, y0, out,
+                                    M, relu, res=res, mask=mask)
+        torch.cuda.synchronize()
+        outs.append((out.float().cpu(), [t.cpu() for t in (scale, shift, mean, rstd, mm, mv)], None if mask is None else mask.cpu()))
+    for a, b in zip(outs[0][1], outs[1][1]):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
+    assert float((outs[0][0] != outs[1][0]).float().mean()) < 1e-3          # same bits wherever the float32 constants agree
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2 ** -7, atol=1e-3)
+
+    # non-finite input: the flag is raised and the unit's outputs are NaN (as the float path's would be)
+    xb = x.clone()
+    xb[0, 0, 0, 0] = float('inf')
+    accb = torch.zeros_like(acc)
+    ops.conv2d_fwd(p, xb, w, y1, stat_acc=accb)
+    scale, shift, mean, rstd, mm, mv = state()
+    out = torch.empty_like(y0)
+    ops.bn_finalize_act_fwd_acc(accb, Cout, M, gamma, beta, 1e-5, 0.9, mm, mv, scale, shift, mean, rstd, y1, out, M, False)
+    torch.cuda.synchronize()
+    assert _acc_totals(accb, 2, Cout)[1] != 0 and bool(torch.isnan(scale).any())
+
+    # ---- backward twin ----
+    w_dg = torch.empty(Cin, 3, 3, Cout, dtype=ACT(), device=dev)
+    ops.repack_dgrad_weights(w, w_dg, Cout, 3, 3, Cin)
+    dy = bf(torch.randn(N, H, W, Cout, generator=g)).to(dev)
+    yb = bf(torch.randn(M, Cin, generator=g) * 1.3 + 0.2).to(dev)
+    mean_b, rstd_b = (torch.randn(Cin, generator=g) * 0.2).to(dev), (torch.rand(Cin, generator=g) + 0.5).to(dev)
+    a1 = (torch.rand(Cin, generator=g) + 0.5).to(dev)
+    maskb = torch.randint(0, 256, (M * Cin // 8,), generator=g, dtype=torch.uint8).to(dev)
+    prow = ops.conv2d_dgrad_bn_rows(p)
+    partial = torch.zeros(prow, 3, Cin, device=dev)
+    dx0 = torch.empty(N, H, W, Cin, dtype=ACT(), device=dev)
+    ops.conv2d_dgrad(p, dy, w_dg, dx0, bn=dict(mask=maskb, y=yb, mean=mean_b, rstd=rstd_b, partial=partial))
+    accq = torch.zeros(ops.acc_words(3, Cin), dtype=torch.int64, device=dev)
+    dx1 = torch.empty_like(dx0)
+    ops.conv2d_dgrad(p, dy, w_dg, dx1, bn=dict(mask=maskb, y=yb, mean=mean_b, rstd=rstd_b, partial=None, acc=accq))
+    torch.cuda.synchronize()
+    assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16))
+    totb, flagb = _acc_totals(accq, 3, Cin)
+    assert flagb == 0
+    ref = partial.double().sum(0).cpu()
+    scale_b = float(ref.abs().max())
+    torch.testing.assert_close(totb[0], ref[0], rtol=1e-10, atol=1e-9 * max(scale_b, 1.0))
+    torch.testing.assert_close(totb[1], ref[1], rtol=1e-10, atol=1e-9 * max(scale_b, 1.0))
+    res_b = []
+    for use_acc in (False, True):
+        dgam, dbet, k1, k2 = [torch.zeros(Cin, device=dev) for _ in range(4)]
+        dyo = torch.empty(M, Cin, dtype=ACT(), device=dev)
+        if use_acc:
+            ops.bn_bwd_finalize_apply_acc(accq, Cin, M, dgam, dbet, k1, k2, dx0, yb, a1, mean_b, rstd_b, M, dyo)
+        else:
+            if prow > 4096:
+                continue
+            ops.bn_bwd_finalize_apply(partial.view(-1), prow, Cin, M, dgam, dbet, k1, k2, dx0, yb, a1, mean_b, rstd_b, M, dyo)
+        torch.cuda.synchronize()
+        res_b.append((dyo.float().cpu(), dgam.cpu(), dbet.cpu(), k1.cpu(), k2.cpu()))
+    if len(res_b) == 2:
+        for a, b in zip(res_b[0][1:], res_b[1][1:]):
+            torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-6 * max(scale_b, 1.0))
+        torch.testing.assert_close(res_b[0][0], res_b[1][0], rtol=2 ** -7, atol=1e-3)

@@ -63,6 +63,12 @@ SIGNATURES = {
     'yolo_conv2d_dgrad': (I, [CP, P, P, P, I, P]),
     'yolo_conv2d_dgrad_bn_rows': (I, [CP]),
     'yolo_conv2d_dgrad_bn': (I, [CP, P, P, P, I, P, P, P, P, P, P, P, P, P, P]),
+    'yolo_conv2d_dgrad_bn_acc': (I, [CP, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P]),
+    'yolo_conv2d_fwd_acc': (I, [CP, P, P, P, P, P, P]),
+    'yolo_acc_words': (I64, [I, I]),
+    'yolo_zero_words': (I, [P, I64, P]),
+    'yolo_bn_finalize_act_fwd_acc': (I, [P, I, F, P, P, F, F, P, P, P, P, P, P, P, P, P, P, I64, I, P]),
+    'yolo_bn_bwd_finalize_apply_acc': (I, [P, I, F, P, P, P, P, P, P, P, P, P, P, I, P, I, I64, P]),
     'yolo_conv2d_dgrad_add': (I, [CP, P, P, P, P, P]),
     'yolo_conv2d_dgrad_classed': (I, [CP]),
     'yolo_conv2d_dgrad_even': (I, [CP, P, P, P, I, P]),

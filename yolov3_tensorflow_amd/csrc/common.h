@@ -76,6 +76,39 @@ __device__ __forceinline__ uint4 pack_bf8(const float* f) {
   return v;
 }
 
+// ---- exact cross-workgroup accumulators (BatchNorm statistics without a finalize launch) ----
+// A float value is added as TWO int64 limbs (value * 2^20 = hi + lo * 2^-40, lo in [0, 2^40)): integer atomics are associative, so the
+// total does not depend on the order in which workgroups arrive -- bit-reproducible, unlike float atomics -- and carries 60 fractional
+// bits (the float32 partial sums are represented exactly unless they are below 2^-36).  Layout of one accumulator block:
+// [YOLO_ACC_NB buckets][Q quantities][2 limbs][C channels] int64, then one flag word (non-zero: a non-finite value was added; the
+// consumer then produces NaN, as the float path would).  Buckets (workgroup index mod YOLO_ACC_NB) spread the same-address contention.
+#define YOLO_ACC_NB 16
+__host__ __device__ inline size_t yolo_acc_block_words(int Q, int C) { return (size_t)YOLO_ACC_NB * Q * 2 * C + 2; }
+__device__ __forceinline__ void yolo_acc_add(long long* block, int Q, int C, int bucket, int q, int c, float v) {
+  if (!(fabsf(v) <= 3.0e38f)) {                        // inf / NaN
+    atomicOr(reinterpret_cast<unsigned long long*>(block + (size_t)YOLO_ACC_NB * Q * 2 * C), 1ull);
+    return;
+  }
+  const double d = (double)v * 1048576.0;              // 2^20
+  const double fl = floor(d);
+  const long long hi = (long long)fl, lo = (long long)((d - fl) * 1099511627776.0);    // 2^40
+  long long* p = block + ((size_t)(bucket * Q + q) * 2) * C + c;
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)hi);
+  atomicAdd(reinterpret_cast<unsigned long long*>(p + C), (unsigned long long)lo);
+}
+// the total of quantity q, channel c over all buckets (NaN if the flag is raised)
+__device__ __forceinline__ double yolo_acc_total(const long long* block, int Q, int C, int q, int c) {
+  long long hi = 0, lo = 0;
+#pragma unroll 4
+  for (int b = 0; b < YOLO_ACC_NB; ++b) {
+    const long long* p = block + ((size_t)(b * Q + q) * 2) * C + c;
+    hi += p[0];
+    lo += p[C];
+  }
+  const double t = (double)hi * (1.0 / 1048576.0) + (double)lo * (1.0 / 1152921504606846976.0);     // 2^-20, 2^-60
+  return block[(size_t)YOLO_ACC_NB * Q * 2 * C] ? __builtin_nan("") : t;
+}
+
 // ---- wave / block reductions (64-wide wavefronts) ----
 // sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: quad butterflies, then half-row and row mirrors
 // (each step is one v_add_f32 with a DPP modifier -- no LDS traffic, unlike __shfl_xor -> ds_bpermute_b32)

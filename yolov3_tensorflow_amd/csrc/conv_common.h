@@ -47,6 +47,9 @@ struct BnEpi {
   const bf16_t* y2; const float* mean2; const float* rstd2;
   float* partial;
   const bf16_t* addend;   // fan-in source of an accumulating data gradient when it is not the output buffer itself (any instantiation)
+  // exact accumulators instead of partial rows (common.h yolo_acc_*): the fused reduce adds its 2 / 3 tile sums there when `partial` is null;
+  // a FORWARD launch (no fused reduce) with stat_sum == null adds its sum / sum of squares there (Q = 2)
+  long long* acc;
 };
 struct Epi { float* ssum; float* ssq; BnEpi bn; };
 
@@ -149,6 +152,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
                                               float* __restrict__ stat_sq, int Kout, int tid, int lane, int wm, int wn, const ClassView& cv,
                                               const BnEpi& bn, int prow, int sg = 0, int b_lo = 0, int b_hi = PT) {
   const int cq = (lane >> 4) * 4;
+  const bool fwd_acc = !BNEPI && !stat_sum && bn.acc;        // forward statistics into accumulators
+  const bool want_stats = stat_sum || fwd_acc;
   float ssum[CT][4], ssq[CT][4];
 #pragma unroll
   for (int a = 0; a < CT; ++a)
@@ -220,7 +225,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
         o.x = pack_bf2(acc[a][b][0], acc[a][b][1]);
         o.y = pack_bf2(acc[a][b][2], acc[a][b][3]);
         *reinterpret_cast<uint2*>(smem + pl * OLD + cl * 2) = o;
-        if (stat_sum && !accumulate && m0 + pl < M) {   // statistics of the values as stored (bf16-rounded)
+        if (want_stats && !accumulate && m0 + pl < M) {   // statistics of the values as stored (bf16-rounded)
           const float r0 = lo2f(o.x), r1 = hi2f(o.x);
           const float r2 = lo2f(o.y), r3 = hi2f(o.y);
           ssum[a][0] += r0; ssum[a][1] += r1; ssum[a][2] += r2; ssum[a][3] += r3;
@@ -285,7 +290,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
           float t = 0.f;
 #pragma unroll 8
           for (int r = 0; r < RG; ++r) t += red[r * BN + cl];
-          bn.partial[((size_t)prow * 3 + q) * ldy + n0 + cl] = t;
+          if (bn.partial) bn.partial[((size_t)prow * 3 + q) * ldy + n0 + cl] = t;
+          else yolo_acc_add(bn.acc, 3, ldy, prow % YOLO_ACC_NB, q, n0 + cl, t);
         }
       }
       return;
@@ -317,7 +323,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
   }
 
   PS_STAMP(16);
-  if (stat_sum) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
+  if (want_stats) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
     __syncthreads();                                  // every wave is done with the staged output tile
     float* red = reinterpret_cast<float*>(smem);      // [2][SG * WM][BN]
     constexpr int WMS = SG * WM;
@@ -340,8 +346,13 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < WMS; ++w) { s += red[w * BN + cl]; q += red[(WMS + w) * BN + cl]; }
-      stat_sum[(size_t)tile_m * Kout + n0 + cl] = s;
-      stat_sq[(size_t)tile_m * Kout + n0 + cl] = q;
+      if (stat_sum) {
+        stat_sum[(size_t)tile_m * Kout + n0 + cl] = s;
+        stat_sq[(size_t)tile_m * Kout + n0 + cl] = q;
+      } else {
+        yolo_acc_add(bn.acc, 2, Kout, tile_m % YOLO_ACC_NB, 0, n0 + cl, s);
+        yolo_acc_add(bn.acc, 2, Kout, tile_m % YOLO_ACC_NB, 1, n0 + cl, q);
+      }
     }
   }
 }

@@ -1072,7 +1072,7 @@ int launch_strip_ws_e(const Gather& g, const void* w, void* y, int ldy, int accu
 
 template <int BM, int BN, int NW, int WS>
 int launch_strip_ws(const Gather& g, const void* w, void* y, int ldy, int accumulate, const Epi& e, int Kout, hipStream_t st) {
-  if (e.bn.partial) return launch_strip_ws_e<BM, BN, NW, WS, true>(g, w, y, ldy, accumulate, e, Kout, st);
+  if (e.bn.y) return launch_strip_ws_e<BM, BN, NW, WS, true>(g, w, y, ldy, accumulate, e, Kout, st);      // (y: the fused BatchNorm reduce is on)
   return launch_strip_ws_e<BM, BN, NW, WS, false>(g, w, y, ldy, accumulate, e, Kout, st);
 }
 
@@ -1111,7 +1111,7 @@ template <int BM, int BN, int NS, bool F32, bool FAST, int NW>
 int launch_tile3(const Gather& g, const void* w, const float* bias, void* y, int ldy, int accumulate, const Epi& e, int Kout,
                  hipStream_t st) {
   if constexpr (!F32) {
-    if (e.bn.partial) return launch_tile3_e<BM, BN, NS, F32, FAST, NW, true>(g, w, bias, y, ldy, accumulate, e, Kout, st);
+    if (e.bn.y) return launch_tile3_e<BM, BN, NS, F32, FAST, NW, true>(g, w, bias, y, ldy, accumulate, e, Kout, st);
   }
   return launch_tile3_e<BM, BN, NS, F32, FAST, NW, false>(g, w, bias, y, ldy, accumulate, e, Kout, st);
 }
@@ -1236,6 +1236,24 @@ extern "C" int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, con
   return launch_fwd<false>(g, w_fwd, bias, y, p->Cout, 0, Epi{stat_sum, stat_sq, {}}, p->Cout, (hipStream_t)stream);
 }
 
+// yolo_conv2d_fwd (16-bit output, no bias) whose BatchNorm statistics go into an exact accumulator block (common.h yolo_acc_*: Q = 2,
+// C = Cout, yolo_acc_words(2, Cout) int64 words, zeroed by the caller before the launch) instead of one partial row per pixel tile: the
+// consumer sums 16 buckets whatever the tile count, so no finalize launch is needed between this kernel and the BatchNorm apply
+extern "C" int yolo_conv2d_fwd_acc(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd, void* y, int64_t* stat_acc,
+                                   void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  YOLO_CHECK_ARG(src1 && w_fwd && y && stat_acc, "null pointer");
+  YOLO_CHECK_ARG(p->C0 == 0 || src0, "C0 > 0 needs src0");
+  YOLO_CHECK_ARG(!yolo_stem_applies(p), "the RGB stem kernel writes statistics rows (yolo_conv2d_fwd)");
+  Gather g = fwd_gather(p, src0, src1);
+  Epi e = {};
+  e.bn.acc = (long long*)stat_acc;
+  return launch_fwd<false>(g, w_fwd, nullptr, y, p->Cout, 0, e, p->Cout, (hipStream_t)stream);
+}
+
+extern "C" int64_t yolo_acc_words(int Q, int C) { return (Q > 0 && C > 0) ? (int64_t)yolo_acc_block_words(Q, C) : 0; }
+
 namespace {
 // conv-transpose as a forward gather over dy with flipped taps: src = (row - (R-1-pad) + tap') / stride
 int dgrad_gather(const yolo_conv_problem* p, const void* dy, Gather* gp, bool even_only = false) {
@@ -1345,8 +1363,15 @@ extern "C" int yolo_conv2d_dgrad_bn_rows(const yolo_conv_problem* p) {
 extern "C" int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend,
                                     const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2,
                                     const float* mean2, const float* rstd2, float* partial, void* stream) {
+  return yolo_conv2d_dgrad_bn_acc(p, dy, w_dgrad, dx, accumulate, addend, relu_mask, y, mean, rstd, y2, mean2, rstd2, partial, nullptr, stream);
+}
+
+// the same with the tile sums added into an exact accumulator block (Q = 3, C = Cin; common.h yolo_acc_*) when partial is null
+extern "C" int yolo_conv2d_dgrad_bn_acc(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend,
+                                        const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2,
+                                        const float* mean2, const float* rstd2, float* partial, int64_t* acc, void* stream) {
   YOLO_CHECK_ARG(dy && w_dgrad && dx, "null pointer");
-  YOLO_CHECK_ARG(y && mean && rstd && partial, "the fused reduce needs y, mean, rstd and partial");
+  YOLO_CHECK_ARG(y && mean && rstd && ((partial != nullptr) != (acc != nullptr)), "the fused reduce needs y, mean, rstd and either partial rows or an accumulator block");
   YOLO_CHECK_ARG(!y2 || (mean2 && rstd2), "y2 needs mean2 and rstd2");
   YOLO_CHECK_ARG((size_t)p->N * p->H * p->W * p->Cin < (1ull << 31), "the fused reduce addresses dx with 32-bit element offsets");
   Gather g;
@@ -1357,6 +1382,7 @@ extern "C" int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, 
   e.bn.y = (const bf16_t*)y; e.bn.mean = mean; e.bn.rstd = rstd;
   e.bn.y2 = (const bf16_t*)y2; e.bn.mean2 = mean2; e.bn.rstd2 = rstd2;
   e.bn.partial = partial;
+  e.bn.acc = (long long*)acc;
   e.bn.addend = (const bf16_t*)addend;             // non-null: the fan-in source instead of dx itself (implies accumulate)
   YOLO_CHECK_ARG(accumulate != 2 || (g.s2 && g.s2_ny == 4 && !addend), "accumulate = 2 needs the parity-class data gradient and no addend");
   return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate == 2 ? 2 : ((accumulate || addend) ? 1 : 0), e, p->Cin, (hipStream_t)stream);

@@ -459,10 +459,10 @@ int ps_launch_e(const yoloconv::Gather& g, const PsPlanOut& pl, const void* w, v
 template <int KG, int MW, int NV, int PT, int CT>
 int ps_launch_v(const yoloconv::Gather& g, const PsPlanOut& pl, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st) {
   if (pl.ring == 4) {
-    if (e.bn.partial) return ps_launch_e<KG, MW, NV, PT, CT, 4, true>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+    if (e.bn.y) return ps_launch_e<KG, MW, NV, PT, CT, 4, true>(g, pl, w, y, ldy, accumulate, e, Kout, st);
     return ps_launch_e<KG, MW, NV, PT, CT, 4, false>(g, pl, w, y, ldy, accumulate, e, Kout, st);
   }
-  if (e.bn.partial) return ps_launch_e<KG, MW, NV, PT, CT, 3, true>(g, pl, w, y, ldy, accumulate, e, Kout, st);
+  if (e.bn.y) return ps_launch_e<KG, MW, NV, PT, CT, 3, true>(g, pl, w, y, ldy, accumulate, e, Kout, st);
   return ps_launch_e<KG, MW, NV, PT, CT, 3, false>(g, pl, w, y, ldy, accumulate, e, Kout, st);
 }
 

@@ -312,6 +312,9 @@ __device__ __forceinline__ void group_reduce(const float* const (&src)[K], int P
   }
 }
 
+// (ACC: the statistics come from an exact accumulator block -- common.h yolo_acc_*, written by yolo_conv2d_fwd_acc -- passed in `psum`:
+// 16 buckets to sum whatever the number of pixel tiles, so the merged launch serves every layer size)
+template <bool ACC>
 __global__ __launch_bounds__(1024) void bn_finalize_act_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int P,
                                                                size_t rstride, int C, float count, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, float momentum,
@@ -336,9 +339,17 @@ __global__ __launch_bounds__(1024) void bn_finalize_act_kernel(const float* __re
     b = beta[c0 + threadIdx.x];
     if (moving_mean && blockIdx.y == 0) { mm0 = moving_mean[c0 + threadIdx.x]; mv0 = moving_var[c0 + threadIdx.x]; }
   }
-  const float* const src[2] = {psum + c0, psq + c0};
   double tot[2];
-  group_reduce<2>(src, P, rstride, tot);
+  if constexpr (ACC) {
+    if (threadIdx.x < FM_CG) {
+      const long long* acc = reinterpret_cast<const long long*>(psum);
+      tot[0] = yolo_acc_total(acc, 2, C, 0, c0 + threadIdx.x);
+      tot[1] = yolo_acc_total(acc, 2, C, 1, c0 + threadIdx.x);
+    }
+  } else {
+    const float* const src[2] = {psum + c0, psq + c0};
+    group_reduce<2>(src, P, rstride, tot);
+  }
   if (threadIdx.x < FM_CG) {
     const int c = c0 + threadIdx.x;
     const double mean = tot[0] / (double)count;
@@ -394,6 +405,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_act_kernel(const float* __re
 
 // backward twin: column sums of the [P][3][C] partial rows (quantities 0 and 1) -> dgamma, dbeta, k1, k2, then
 // dy (=|+=) a (g - k1 - xhat k2) and the optional shortcut copy dres (=|+=) g on the workgroup's row slice
+template <bool ACC>
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, int P, size_t rstride, size_t qstride,
                                                                      int C, float count, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                      float* __restrict__ k1, float* __restrict__ k2,
@@ -411,9 +423,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_apply_kernel(const float
   if (m_lo + r0 < m_hi) { gv0 = ld16(gin + e0); yv0 = ld16(y + e0); }
   float ca[8], cmu[8], crs[8];
   ld8f(a1 + c0 + ch * 8, ca); ld8f(mean + c0 + ch * 8, cmu); ld8f(rstd + c0 + ch * 8, crs);
-  const float* const src[2] = {partial + c0, partial + qstride + c0};
   double tot[2];
-  group_reduce<2>(src, P, rstride, tot);
+  if constexpr (ACC) {                                  // accumulator block of yolo_conv2d_dgrad_bn_acc (Q = 3: sum g, sum g xhat, [sum g xhat2])
+    if (threadIdx.x < FM_CG) {
+      const long long* acc = reinterpret_cast<const long long*>(partial);
+      tot[0] = yolo_acc_total(acc, 3, C, 0, c0 + threadIdx.x);
+      tot[1] = yolo_acc_total(acc, 3, C, 1, c0 + threadIdx.x);
+    }
+  } else {
+    const float* const src[2] = {partial + c0, partial + qstride + c0};
+    group_reduce<2>(src, P, rstride, tot);
+  }
   if (threadIdx.x < FM_CG) {
     const int c = c0 + threadIdx.x;
     const float v1 = (float)(tot[0] / (double)count), v2 = (float)(tot[1] / (double)count);
@@ -1388,9 +1408,40 @@ extern "C" int yolo_bn_finalize_act_fwd(const float* psum, const float* psq, int
   YOLO_CHECK_ARG(!relu_mask || relu, "relu_mask needs relu");
   const int ms = fm_slices(M, C);
   const int rows_per = (int)((M + ms - 1) / ms);
-  hipLaunchKernelGGL(bn_finalize_act_kernel, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, psum, psq, P, (size_t)row_stride, C, count,
+  hipLaunchKernelGGL(bn_finalize_act_kernel<false>, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, psum, psq, P, (size_t)row_stride, C, count,
                      gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd, (const bf16_t*)y, (const bf16_t*)res,
                      (bf16_t*)out, relu_mask, (int)M, rows_per, relu);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+// the same unit with its statistics in an exact accumulator block (yolo_conv2d_fwd_acc): any number of pixel tiles, no finalize launch
+extern "C" int yolo_bn_finalize_act_fwd_acc(const int64_t* stat_acc, int C, float count, const float* gamma, const float* beta, float eps,
+                                            float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, float* mean,
+                                            float* rstd, const void* y, const void* res, void* out, uint8_t* relu_mask, int64_t M, int relu,
+                                            void* stream) {
+  YOLO_CHECK_ARG(stat_acc && gamma && beta && scale && shift && mean && rstd && y && out, "null pointer");
+  YOLO_CHECK_ARG(C > 0 && C % FM_CG == 0 && count > 0.f && M > 0 && M * (int64_t)C < (int64_t)1 << 31, "bad size (C must be a multiple of 32)");
+  YOLO_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "moving_mean and moving_var go together");
+  YOLO_CHECK_ARG(!relu_mask || relu, "relu_mask needs relu");
+  const int ms = fm_slices(M, C);
+  const int rows_per = (int)((M + ms - 1) / ms);
+  hipLaunchKernelGGL(bn_finalize_act_kernel<true>, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, (const float*)stat_acc, (const float*)nullptr,
+                     YOLO_ACC_NB, (size_t)0, C, count, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd, (const bf16_t*)y,
+                     (const bf16_t*)res, (bf16_t*)out, relu_mask, (int)M, rows_per, relu);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+__global__ void zero_words_kernel(unsigned long long* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0ull;
+}
+// zero n 8-byte words (the accumulator blocks of a step, once, before its first convolution): a kernel, so that it is part of a recorded
+// launch sequence like everything else
+extern "C" int yolo_zero_words(int64_t* p, int64_t n, void* stream) {
+  YOLO_CHECK_ARG(p && n > 0, "bad argument");
+  const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)p, (size_t)n);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
@@ -1404,8 +1455,22 @@ extern "C" int yolo_bn_bwd_finalize_apply(const float* partial, int P, int64_t r
   YOLO_CHECK_ARG(q_stride >= C && row_stride >= 2 * q_stride, "bad strides");
   const int ms = fm_slices(M, C);
   const int rows_per = (int)((M + ms - 1) / ms);
-  hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,
+  hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<false>, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,
                      (size_t)q_stride, C, count, dgamma, dbeta, k1, k2, (const bf16_t*)g, (const bf16_t*)y, a1, mean, rstd, (bf16_t*)dy, acc_dy,
+                     (bf16_t*)dres, acc_dres, (int)M, rows_per);
+  YOLO_LAUNCH_CHECK();
+  return YOLO_OK;
+}
+
+extern "C" int yolo_bn_bwd_finalize_apply_acc(const int64_t* acc, int C, float count, float* dgamma, float* dbeta, float* k1, float* k2, const void* g,
+                                              const void* y, const float* a1, const float* mean, const float* rstd, void* dy, int acc_dy, void* dres,
+                                              int acc_dres, int64_t M, void* stream) {
+  YOLO_CHECK_ARG(acc && k1 && k2 && g && y && a1 && mean && rstd && dy, "null pointer");
+  YOLO_CHECK_ARG(C > 0 && C % FM_CG == 0 && count > 0.f && M > 0 && M * (int64_t)C < (int64_t)1 << 31, "bad size (C must be a multiple of 32)");
+  const int ms = fm_slices(M, C);
+  const int rows_per = (int)((M + ms - 1) / ms);
+  hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<true>, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, (const float*)acc, YOLO_ACC_NB, (size_t)0,
+                     (size_t)0, C, count, dgamma, dbeta, k1, k2, (const bf16_t*)g, (const bf16_t*)y, a1, mean, rstd, (bf16_t*)dy, acc_dy,
                      (bf16_t*)dres, acc_dres, (int)M, rows_per);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;

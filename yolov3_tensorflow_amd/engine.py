@@ -197,6 +197,12 @@ class Graph(object):
         self.stem_bwd = os.environ.get('YOLO_STEM_BWD', '1') != '0'
         # small maps: BatchNorm finalize + apply in one launch when a unit has at most this many partial rows (0 = never; forward and
         # backward; ops.bn_finalize_act_fwd / ops.bn_bwd_finalize_apply)
+        # BatchNorm statistics through exact int64 accumulators (ops.conv2d_fwd(stat_acc=...), yolo_acc_*): the producing convolution adds
+        # its tile sums with integer atomics -- associative, so bit-reproducible -- into 16 buckets, and the unit's finalize + apply run as ONE
+        # launch whatever the layer size (with partial ROWS that only pays below ~128 rows): the separate finalize launches (~5 us of
+        # dependent-launch floor each, forward and backward) disappear for every plain conv -> BatchNorm unit.  YOLO_STAT_ACC=0 for A/B runs.
+        self.stat_acc = os.environ.get('YOLO_STAT_ACC', '1') != '0'
+        self.acc_buf = None
         self.fin_merge_rows = int(os.environ.get('YOLO_FIN_MERGE_ROWS', '128'))
         self.fin_merge_bwd_rows = int(os.environ.get('YOLO_FIN_MERGE_BWD_ROWS', str(self.fin_merge_rows)))
         self.vals = []
@@ -474,6 +480,7 @@ class Graph(object):
                                 ops.conv2d_dgrad_classed(b.y.p)):
                             a.even_only = True
                             b.acc = [2]
+        self.plan_accumulators()
         # gradient buckets for data-parallel overlap, by backbone stage (parameters are laid out in creation order, backward runs in reverse):
         #   [first stride-32 conv, n)   module512 + the three heads, ~70 % of the parameters: complete ~40 % into the backward pass
         #   [first stride-8 conv, that) the stride-8 / stride-16 stages
@@ -553,6 +560,35 @@ class Graph(object):
         self.bucket_done(*self.bucket_ranges[-1], last=True)
         if side is not None and not self.tail_on_main:
             self.stream_wait(torch.cuda.current_stream(self.dev), side)
+
+    def plan_accumulators(self):
+        """exact accumulator blocks (one flat int64 buffer, zeroed by ONE launch at the start of every step) for the BatchNorm units whose
+        finalize + apply can run as one launch: forward statistics from the producing convolution's epilogue, backward tile sums from the
+        epilogue of the data gradient that completes the unit's output gradient"""
+        self.acc_buf = None
+        if not self.stat_acc:
+            return
+        reqs, total = [], 0
+        for op in self.tape:
+            if not isinstance(op, ApplyOp):
+                continue
+            if op.acc_fwd_eligible():
+                reqs.append((op, 'f', total))
+                total += ops.acc_words(2, op.C)
+            if op.acc_bwd_eligible():
+                reqs.append((op, 'b', total))
+                total += ops.acc_words(3, op.C)
+        if not reqs:
+            return
+        self.acc_buf = torch.zeros(total, dtype=torch.int64, device=self.dev)
+        for op, kind, off in reqs:
+            if kind == 'f':
+                op.acc_f = self.acc_buf[off:off + ops.acc_words(2, op.C)]
+                op.m_src.acc_fwd = op.acc_f
+            else:
+                op.acc_b = self.acc_buf[off:off + ops.acc_words(3, op.C)]
+                op.producer.bn_epi = dict(op.producer.bn_epi, acc=op.acc_b, partial=None)
+        self.fwd.insert(0, lambda: ops.zero_words(self.acc_buf))
 
     def stream_wait(self, waiter, signaler):
         """``waiter`` (a torch stream) waits for everything queued on ``signaler`` so far.  Eager mode goes through the library
@@ -731,6 +767,10 @@ class ConvOp(object):
 
     def forward(self):
         y = self.y
+        acc = getattr(y, 'acc_fwd', None)
+        if acc is not None and self.g.training:          # statistics into the unit's accumulator block (Graph.plan_accumulators)
+            ops.conv2d_fwd(y.p, self.src1.buf, self.w, y.buf, src0=None if self.src0 is None else self.src0.buf, stat_acc=acc)
+            return
         ops.conv2d_fwd(y.p, self.src1.buf, self.w, y.buf, src0=None if self.src0 is None else self.src0.buf, bias=self.bias,
                        stat_sum=self.ssum, stat_sq=self.ssq)
 
@@ -865,6 +905,23 @@ class ApplyOp(object):
             psum, psq, P, rs = flat, flat[self.C:], self.P, 2 * self.C
         bn.fwd_finalize(psum, psq, P, rs, self.M, self.g.training)
 
+    def acc_fwd_eligible(self):
+        """forward statistics through an accumulator block: one plain BatchNorm over a (non-stem) convolution's output, nothing normalised
+        on the other operand -- the merged finalize + apply launch then serves the unit at any size"""
+        g, mb, m = self.g, self.m_bn, self.m_src
+        if not (g.stat_acc and mb is not None and self.o_bn is None and m.kind == 'conv' and isinstance(mb, BNState) and len(mb.parts) == 1
+                and self.C % 32 == 0 and getattr(m, 'stats', None) is not None):
+            return False
+        return ops.conv2d_fwd_plan(m.p)['family'] != 'stem'
+
+    def acc_bwd_eligible(self):
+        """backward: the producer's epilogue leaves the unit's tile sums; one BatchNorm, the unit writes its own dy (no alias)"""
+        mb = self.m_bn
+        if not (self.g.stat_acc and self.producer is not None):
+            return False
+        y1, b1, y2, b2 = self._reduce_operands()
+        return b2 is None and b1 is mb and isinstance(mb, BNState) and len(mb.parts) == 1 and self.C % 32 == 0 and not self.skip_dy
+
     def _merged_fwd(self):
         """(psum, psq, P, row_stride) if this unit's finalize + apply run as one launch: training, one plain BatchNorm over a conv output
         with few partial rows, no BatchNorm on the other operand"""
@@ -876,6 +933,12 @@ class ApplyOp(object):
         return st if st[2] <= g.fin_merge_rows else None
 
     def forward(self):
+        if getattr(self, 'acc_f', None) is not None and self.g.training:
+            mb = self.m_bn
+            ops.bn_finalize_act_fwd_acc(self.acc_f, self.C, self.M, mb.v_gamma, mb.v_beta, BN_EPSILON, self.g.bn_momentum, mb.moving_mean,
+                                        mb.moving_var, mb.scale, mb.shift, mb.mean, mb.rstd, self.m_src.buf, self.out.buf, self.M, self.relu,
+                                        res=None if self.o_src is None else self.o_src.buf, mask=self.mask)
+            return
         st = self._merged_fwd()
         if st is not None:
             mb = self.m_bn
@@ -971,6 +1034,12 @@ class ApplyOp(object):
         if self.producer is not None:
             # out.grad already holds the masked gradient and self.fpartial its tile sums (left by the producer's epilogue)
             y1, b1, y2, b2 = self._reduce_operands()
+            if getattr(self, 'acc_b', None) is not None:
+                dres = o.grad if (o is not None and not self.skip_dres) else None
+                ops.bn_bwd_finalize_apply_acc(self.acc_b, self.C, self.M, mb.v_dgamma, mb.v_dbeta, mb.k1, mb.k2, out.grad, m.buf, mb.scale, mb.mean,
+                                              mb.rstd, self.M, m.dy if self.m_dst == 'dy' else m.grad, acc_dy=self.m_acc, dres=dres,
+                                              acc_dres=self.o_acc)
+                return
             if (b2 is None and b1 is mb and isinstance(mb, BNState) and len(mb.parts) == 1 and self.C % 32 == 0 and not self.skip_dy
                     and 0 < self.frows <= self.g.fin_merge_bwd_rows):
                 dres = o.grad if (o is not None and not self.skip_dres) else None          # (ob is None here: b2 is None and b1 is mb)

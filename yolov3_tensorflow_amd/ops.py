@@ -74,7 +74,24 @@ def conv2d_fwd_plan(p):
                 ring=info[6])
 
 
-def conv2d_fwd(p, src1, w_fwd, y, src0=None, bias=None, stat_sum=None, stat_sq=None):
+def acc_words(Q, Cc):
+    """int64 words of one exact accumulator block for Q quantities of Cc channels (yolo_acc_words)"""
+    return int(_lib.load().yolo_acc_words(int(Q), int(Cc)))
+
+
+def zero_words(t):
+    """zero an int64 tensor with a library launch (part of a recorded step, unlike a torch fill)"""
+    check(_lib.load().yolo_zero_words(_p(t), t.numel(), _stream()), 'yolo_zero_words')
+
+
+def conv2d_fwd(p, src1, w_fwd, y, src0=None, bias=None, stat_sum=None, stat_sq=None, stat_acc=None):
+    """``stat_acc``: an exact accumulator block (acc_words(2, Cout) int64, zeroed this step) that receives the BatchNorm statistics instead
+    of the per-tile rows stat_sum / stat_sq (yolo_conv2d_fwd_acc)"""
+    if stat_acc is not None:
+        if bias is not None or stat_sum is not None or y.dtype == torch.float32:
+            raise ValueError('stat_acc goes with a 16-bit output, no bias and no statistics rows')
+        check(_lib.load().yolo_conv2d_fwd_acc(C.byref(p), _p(src0), _p(src1), _p(w_fwd), _p(y), _p(stat_acc), _stream()), 'yolo_conv2d_fwd_acc')
+        return
     check(_lib.load().yolo_conv2d_fwd(C.byref(p), _p(src0), _p(src1), _p(w_fwd), _p(bias), _p(y),
                                       1 if y.dtype == torch.float32 else 0, _p(stat_sum), _p(stat_sq), _stream()), 'yolo_conv2d_fwd')
 
@@ -94,6 +111,11 @@ def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False, bn=None, addend=None, eve
             check(_lib.load().yolo_conv2d_dgrad_add(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), _p(addend), _stream()), 'yolo_conv2d_dgrad_add')
         else:
             check(_lib.load().yolo_conv2d_dgrad(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _stream()), 'yolo_conv2d_dgrad')
+        return
+    if bn.get('acc') is not None:            # tile sums into an exact accumulator block (acc_words(3, Cin)) instead of partial rows
+        check(_lib.load().yolo_conv2d_dgrad_bn_acc(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _p(addend), _p(bn.get('mask')),
+                                                   _p(bn['y']), _p(bn['mean']), _p(bn['rstd']), _p(bn.get('y2')), _p(bn.get('mean2')),
+                                                   _p(bn.get('rstd2')), None, _p(bn['acc']), _stream()), 'yolo_conv2d_dgrad_bn_acc')
         return
     check(_lib.load().yolo_conv2d_dgrad_bn(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _p(addend), _p(bn.get('mask')), _p(bn['y']),
                                            _p(bn['mean']), _p(bn['rstd']), _p(bn.get('y2')), _p(bn.get('mean2')), _p(bn.get('rstd2')),
@@ -195,6 +217,20 @@ def bn_finalize_act_fwd(psum, psq, P, row_stride, Cc, count, gamma, beta, eps, m
     check(_lib.load().yolo_bn_finalize_act_fwd(_p(psum), _p(psq), P, row_stride, Cc, float(count), _p(gamma), _p(beta), eps, momentum,
                                                _p(moving_mean), _p(moving_var), _p(scale), _p(shift), _p(mean), _p(rstd), _p(y), _p(res),
                                                _p(out), _p(mask), M, int(bool(relu)), _stream()), 'yolo_bn_finalize_act_fwd')
+
+
+def bn_finalize_act_fwd_acc(stat_acc, Cc, count, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd, y, out, M, relu,
+                            res=None, mask=None):
+    """finalize + apply in one launch with the statistics read from an exact accumulator block (conv2d_fwd(stat_acc=...)): any layer size"""
+    check(_lib.load().yolo_bn_finalize_act_fwd_acc(_p(stat_acc), Cc, float(count), _p(gamma), _p(beta), eps, momentum, _p(moving_mean),
+                                                   _p(moving_var), _p(scale), _p(shift), _p(mean), _p(rstd), _p(y), _p(res), _p(out), _p(mask), M,
+                                                   int(bool(relu)), _stream()), 'yolo_bn_finalize_act_fwd_acc')
+
+
+def bn_bwd_finalize_apply_acc(acc, Cc, count, dgamma, dbeta, k1, k2, g, y, a1, mean, rstd, M, dy, acc_dy=False, dres=None, acc_dres=False):
+    check(_lib.load().yolo_bn_bwd_finalize_apply_acc(_p(acc), Cc, float(count), _p(dgamma), _p(dbeta), _p(k1), _p(k2), _p(g), _p(y), _p(a1),
+                                                     _p(mean), _p(rstd), _p(dy), int(bool(acc_dy)), _p(dres), int(bool(acc_dres)), M, _stream()),
+          'yolo_bn_bwd_finalize_apply_acc')
 
 
 def bn_bwd_finalize_apply(partial, P, Cc, count, dgamma, dbeta, k1, k2, g, y, a1, mean, rstd, M, dy, acc_dy=False, dres=None, acc_dres=False,
