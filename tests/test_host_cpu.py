@@ -142,9 +142,10 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
         last_is_conv = bool(w) and isinstance(w[-1], engine.ConvOp) and w[-1].y.x is op.out
         assert (op.producer is not None) == (last_is_conv and (op.m_bn is not None or op.o_bn is not None))
         if op.producer is not None:
+            from yolov3_tensorflow_amd import ops as ops_real
             epi = op.producer.bn_epi
             if getattr(op, 'acc_b', None) is not None:        # tile sums into the unit's accumulator block (3 quantities x Cin) instead of rows
-                assert epi['partial'] is None and epi['acc'] is op.acc_b and op.acc_b.numel() == 16 * 3 * 2 * op.C + 2
+                assert epi['partial'] is None and epi['acc'] is op.acc_b and op.acc_b.numel() == ops_real.acc_words(3, op.C)
             else:
                 assert epi['partial'] is op.fpartial and op.fpartial.shape[1:] == (3, op.C) and float(op.fpartial.abs().sum()) == 0.0
     # (the mocked single-launch kernel 'declines', so every unit without a producer also takes the three-kernel path here)

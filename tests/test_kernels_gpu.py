@@ -1254,9 +1254,10 @@ def test_fp16_build_strip_and_wgrad_strip(dev, fp16):
 
 
 def _acc_totals(acc, Q, C):
-    """decode an exact accumulator block (common.h yolo_acc_*): [16 buckets][Q][2 limbs][C] int64 + flag -> (Q, C) float64 totals, flag"""
-    a = acc[:16 * Q * 2 * C].reshape(16, Q, 2, C).sum(0).cpu()
-    return a[:, 0].double() * 2.0 ** -20 + a[:, 1].double() * 2.0 ** -60, int(acc[16 * Q * 2 * C].item())
+    """decode an exact accumulator block (common.h yolo_acc_*): [buckets][Q][2 limbs][C] int64 + flag -> (Q, C) float64 totals, flag"""
+    nb = (acc.numel() - 2) // (Q * 2 * C)
+    a = acc[:nb * Q * 2 * C].reshape(nb, Q, 2, C).sum(0).cpu()
+    return a[:, 0].double() * 2.0 ** -20 + a[:, 1].double() * 2.0 ** -60, int(acc[nb * Q * 2 * C].item())
 
 
 @pytest.mark.parametrize('case', [(4, 52, 52, 128, 64, True), (3, 104, 104, 64, 64, False), (6, 13, 13, 256, 512, True), (5, 26, 30, 64, 128, False)])

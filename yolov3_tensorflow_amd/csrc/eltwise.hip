@@ -36,6 +36,15 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[K][8], int C, fl
 
 __device__ __forceinline__ uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void st16(bf16_t* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+// streamed-once operands (nt: the line is not kept in L2 behind the read); selected at run time by the "ew_nt" tuning for A/B runs
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16s(const bf16_t* p, bool nt) {
+  if (nt) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
 // eight consecutive floats of a per-channel vector (c is a multiple of 8: 32-byte aligned)
 __device__ __forceinline__ void ld8f(const float* __restrict__ p, float (&v)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __
                                                                 const float* __restrict__ shift, const bf16_t* __restrict__ res,
                                                                 const float* __restrict__ scale2, const float* __restrict__ shift2,
                                                                 bf16_t* __restrict__ out, size_t nchunks, int C, int relu,
-                                                                uint8_t* __restrict__ mask) {
+                                                                uint8_t* __restrict__ mask, int nt) {
   const int CV = C >> 3;
   // the grid stride is a multiple of CV (CV divides the 256 threads of a workgroup): a thread keeps its channel chunk, so the per-channel
   // constants are loaded ONCE -- in the loop they were 16-32 four-byte loads per 16-byte chunk, and the address units, not HBM, set the pace
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __
   if (scale2) { ld8f(scale2 + c, sc2); ld8f(shift2 + c, sh2); }
   for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_THREADS) {
     float v[8];
-    const uint4 yv = ld16(y + i * 8);
+    const uint4 yv = ld16s(y + i * 8, nt & 2);
     uint4 rv = make_uint4(0u, 0u, 0u, 0u);
     if (res) rv = ld16(res + i * 8);                  // both reads in flight before the first use
     unpack_bf8(yv, v);
@@ -262,6 +271,130 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_kernel(const bf16_t* __
       for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
     }
     st16(out + i * 8, pack_bf8(v));
+  }
+}
+
+// ---- finalize from an exact accumulator block INSIDE the streaming apply kernels (large maps) ----
+// The merged launches below keep one 1024-thread workgroup per CU: fine where the launch floor dominates, slower than bn_act_fwd_kernel's 8
+// workgroups per CU once the tensor is tens of MB.  Here every 256-thread workgroup of the streaming kernel first derives the per-channel
+// constants itself: thread c sums the block's 8 buckets for channel c (32 eight-byte loads, L2 hits), LDS hands the 8 channels of a
+// thread's chunk column over, workgroup 0 publishes what the backward pass / the moving averages need.  ~1 us of prologue per workgroup
+// (they all live for the whole launch), no finalize launch, no partial rows.
+__global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_acc_kernel(const long long* __restrict__ acc, float count, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float eps, float momentum,
+                                                                    float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                                    float* __restrict__ scale_o, float* __restrict__ shift_o,
+                                                                    float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                                    const bf16_t* __restrict__ y, const bf16_t* __restrict__ res,
+                                                                    bf16_t* __restrict__ out, size_t nchunks, int C, int relu,
+                                                                    uint8_t* __restrict__ mask) {
+  extern __shared__ float s_const[];                   // [2][C]
+  for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+    const double mean = yolo_acc_total(acc, 2, C, 0, c) / (double)count;
+    double var = yolo_acc_total(acc, 2, C, 1, c) / (double)count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd, sh = beta[c] - (float)mean * sc;
+    s_const[c] = sc;
+    s_const[C + c] = sh;
+    if (blockIdx.x == 0) {
+      scale_o[c] = sc;
+      shift_o[c] = sh;
+      mean_o[c] = (float)mean;
+      rstd_o[c] = rstd;
+      if (moving_mean) {
+        const double unb = count > 1.f ? var * ((double)count / ((double)count - 1.0)) : var;
+        moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
+        moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unb;
+      }
+    }
+  }
+  __syncthreads();
+  const int CV = C >> 3;
+  const int c = (int)(((size_t)blockIdx.x * EW_THREADS + threadIdx.x) % CV) * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = s_const[c + j]; sh[j] = s_const[C + c + j]; }
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_THREADS) {
+    float v[8];
+    const uint4 yv = ld16(y + i * 8);
+    uint4 rv = make_uint4(0u, 0u, 0u, 0u);
+    if (res) rv = ld16(res + i * 8);
+    unpack_bf8(yv, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+    if (res) {
+      float r[8];
+      unpack_bf8(rv, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    if (relu) {
+      if (mask) {
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m |= (v[j] > 0.f ? 1u : 0u) << j;
+        mask[i] = (uint8_t)m;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st16(out + i * 8, pack_bf8(v));
+  }
+}
+
+// backward twin: dgamma / dbeta / k1 / k2 from the block the data gradient's epilogue filled (Q = 3), then dy (=|+=) a (g - k1 - xhat k2)
+// and the optional shortcut copy dres (=|+=) g, g = the masked gradient
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_acc_kernel(const long long* __restrict__ acc, float count, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta, float* __restrict__ k1_o, float* __restrict__ k2_o,
+                                                                      const bf16_t* __restrict__ gin, const bf16_t* __restrict__ y,
+                                                                      const float* __restrict__ a1, const float* __restrict__ mean,
+                                                                      const float* __restrict__ rstd, bf16_t* __restrict__ dy, int acc_dy,
+                                                                      bf16_t* __restrict__ dres, int acc_dres, size_t nchunks, int C) {
+  extern __shared__ float s_const[];                   // [2][C]
+  for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+    const double t0 = yolo_acc_total(acc, 3, C, 0, c), t1 = yolo_acc_total(acc, 3, C, 1, c);
+    const float v1 = (float)(t0 / (double)count), v2 = (float)(t1 / (double)count);
+    s_const[c] = v1;
+    s_const[C + c] = v2;
+    if (blockIdx.x == 0) {
+      if (dgamma) dgamma[c] = (float)t1;
+      if (dbeta) dbeta[c] = (float)t0;
+      k1_o[c] = v1;
+      k2_o[c] = v2;
+    }
+  }
+  __syncthreads();
+  const int CV = C >> 3;
+  const int c = (int)(((size_t)blockIdx.x * EW_THREADS + threadIdx.x) % CV) * 8;
+  float ca[8], cmu[8], crs[8], ck1[8], ck2[8];
+  ld8f(a1 + c, ca); ld8f(mean + c, cmu); ld8f(rstd + c, crs);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ck1[j] = s_const[c + j]; ck2[j] = s_const[C + c + j]; }
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_THREADS) {
+    const uint4 gv = ld16(gin + i * 8), yv = ld16(y + i * 8);
+    uint4 ov = make_uint4(0u, 0u, 0u, 0u), rv = ov;
+    if (acc_dy) ov = ld16(dy + i * 8);
+    if (dres && acc_dres) rv = ld16(dres + i * 8);
+    float g[8], v[8], o[8];
+    unpack_bf8(gv, g);
+    unpack_bf8(yv, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = ca[j] * (g[j] - ck1[j] - (v[j] - cmu[j]) * crs[j] * ck2[j]);
+    if (acc_dy) {
+      unpack_bf8(ov, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += v[j];
+    }
+    st16(dy + i * 8, pack_bf8(o));
+    if (dres) {
+      if (acc_dres) {
+        unpack_bf8(rv, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += v[j];
+      }
+      st16(dres + i * 8, pack_bf8(g));
+    }
   }
 }
 
@@ -535,8 +668,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_pool_fwd_kernel(const bf16_t* _
 // ------------------------------------------------------------------------------------------------------------------
 struct PlainGrad {
   const bf16_t* dout; const bf16_t* out; int relu; int C;
-  __device__ __forceinline__ void load(size_t row, int cv, float (&g)[8]) const {
-    unpack_bf8(ld16(dout + row * C + cv * 8), g);
+  __device__ __forceinline__ void load(size_t row, int cv, float (&g)[8], bool nt = false) const {
+    unpack_bf8(ld16s(dout + row * C + cv * 8, nt), g);
     if (relu == 2) {           // `out` is the forward pass's byte mask [rows][C / 8]
       const unsigned m = reinterpret_cast<const uint8_t*>(out)[row * (size_t)(C >> 3) + cv];
 #pragma unroll
@@ -552,7 +685,7 @@ struct PlainGrad {
 
 struct PoolGrad {  // rows index the PRE-pool map [N][H][W]
   const bf16_t* dout; const bf16_t* out; const uint8_t* argmax; int relu; int C; int H, W, Ho, Wo, pt, pl;
-  __device__ __forceinline__ void load(size_t row, int cv, float (&g)[8]) const {
+  __device__ __forceinline__ void load(size_t row, int cv, float (&g)[8], bool = false) const {
     const int w = (int)(row % W);
     size_t t = row / W;
     const int h = (int)(t % H);
@@ -724,7 +857,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf
                                                                   const float* __restrict__ mean2, const float* __restrict__ rstd2,
                                                                   const float* __restrict__ k1b, const float* __restrict__ k2b,
                                                                   bf16_t* __restrict__ dy2, bf16_t* __restrict__ dres, int acc_dres,
-                                                                  size_t M, int C) {
+                                                                  size_t M, int C, int nt) {
   const int CV = C >> 3;
   const size_t total = M * CV;
   // a thread keeps its channel chunk (the grid stride is a multiple of CV): the per-channel constants live in registers, not in 40-80
@@ -740,12 +873,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(G gp, const bf
     const size_t row = i / CV;
     // every read of the chunk is requested before the first use (one load in flight per thread left the kernel latency-bound)
     uint4 yv = make_uint4(0u, 0u, 0u, 0u), ov = yv, y2v = yv, rv = yv;
-    if (dy && a1) yv = ld16(y + i * 8);
+    if (dy && a1) yv = ld16s(y + i * 8, nt & 1);
     if (dy && acc_dy) ov = ld16(dy + i * 8);
     if (HAS2) y2v = ld16(y2 + i * 8);
     if (dres && acc_dres) rv = ld16(dres + i * 8);
     float g[8], v[8], o[8];
-    gp.load(row, cv, g);
+    gp.load(row, cv, g, nt & 1);
     if (dy) {
       if (a1) {
         unpack_bf8(yv, v);
@@ -1303,6 +1436,11 @@ inline int reduce_grid(int M, int C) {
 }  // namespace
 
 // ---- host side of the fused backward
+// "ew_nt" tuning (bit mask): 1 = the backward apply streams g and y with non-temporal loads, 2 = the forward apply y.  Both tensors are read
+// exactly once by these launches and not again before they have left the caches anyway; not keeping their lines behind the read leaves L2 to
+// the operands the concurrent convolutions re-read.  Measured on the whole step (3 alternating runs each, one box): +0.75..1.0 %.  The same
+// hint on the fused data-gradient epilogue's y / addend reads LOST 0.5 %, on the optimizer's streams it was neutral: not applied there.
+int g_ew_nt = 3;
 int g_pool_scatter = 1;         // "pool_scatter": 1 = scatter form of the stem's pooled backward apply (C <= 64), 0 = gather form
 int g_fused_min_chunks = 3;
 int g_fused_small_chunks = 0;   // "bn_fused_small_grid": workgroups of the small-tensor launch; 0 = small tensors use the three-kernel path
@@ -1387,6 +1525,7 @@ extern "C" int yolo_bn_bwd_finalize_grouped(const float* partial, int P, int64_t
   return YOLO_OK;
 }
 
+int64_t g_acc_stream_elems = 2000000;   // "acc_stream_kelems" tuning (x1000): tensors from this many elements take the streaming accumulator kernels
 namespace {
 // row slices of the merged small-map launches: ~256 workgroups in all, at least 256 rows each
 int fm_slices(int64_t M, int C) {
@@ -1424,6 +1563,14 @@ extern "C" int yolo_bn_finalize_act_fwd_acc(const int64_t* stat_acc, int C, floa
   YOLO_CHECK_ARG(C > 0 && C % FM_CG == 0 && count > 0.f && M > 0 && M * (int64_t)C < (int64_t)1 << 31, "bad size (C must be a multiple of 32)");
   YOLO_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "moving_mean and moving_var go together");
   YOLO_CHECK_ARG(!relu_mask || relu, "relu_mask needs relu");
+  if (M * (int64_t)C >= g_acc_stream_elems && chan_ok(C)) {      // large tensor: the streaming kernel derives its constants itself
+    const size_t nch = (size_t)M * (C / 8);
+    hipLaunchKernelGGL(bn_act_fwd_acc_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 2 * C * sizeof(float), (hipStream_t)stream, (const long long*)stat_acc,
+                       count, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd, (const bf16_t*)y, (const bf16_t*)res,
+                       (bf16_t*)out, nch, C, relu, relu_mask);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+  }
   const int ms = fm_slices(M, C);
   const int rows_per = (int)((M + ms - 1) / ms);
   hipLaunchKernelGGL(bn_finalize_act_kernel<true>, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, (const float*)stat_acc, (const float*)nullptr,
@@ -1467,6 +1614,13 @@ extern "C" int yolo_bn_bwd_finalize_apply_acc(const int64_t* acc, int C, float c
                                               int acc_dres, int64_t M, void* stream) {
   YOLO_CHECK_ARG(acc && k1 && k2 && g && y && a1 && mean && rstd && dy, "null pointer");
   YOLO_CHECK_ARG(C > 0 && C % FM_CG == 0 && count > 0.f && M > 0 && M * (int64_t)C < (int64_t)1 << 31, "bad size (C must be a multiple of 32)");
+  if (M * (int64_t)C >= g_acc_stream_elems && chan_ok(C)) {
+    const size_t nch = (size_t)M * (C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_acc_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 2 * C * sizeof(float), (hipStream_t)stream, (const long long*)acc, count,
+                       dgamma, dbeta, k1, k2, (const bf16_t*)g, (const bf16_t*)y, a1, mean, rstd, (bf16_t*)dy, acc_dy, (bf16_t*)dres, acc_dres, nch, C);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+  }
   const int ms = fm_slices(M, C);
   const int rows_per = (int)((M + ms - 1) / ms);
   hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<true>, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, (const float*)acc, YOLO_ACC_NB, (size_t)0,
@@ -1483,7 +1637,7 @@ extern "C" int yolo_bn_act_fwd(const void* y, const float* scale, const float* s
   YOLO_CHECK_ARG(!res_scale || res, "res_scale needs res");
   const size_t nch = (size_t)M * (C / 8);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, scale, shift,
-                     (const bf16_t*)res, res_scale, res_shift, (bf16_t*)out, nch, C, relu, (uint8_t*)nullptr);
+                     (const bf16_t*)res, res_scale, res_shift, (bf16_t*)out, nch, C, relu, (uint8_t*)nullptr, g_ew_nt);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
@@ -1495,7 +1649,7 @@ extern "C" int yolo_bn_act_fwd_mask(const void* y, const float* scale, const flo
   YOLO_CHECK_ARG(!res_scale || res, "res_scale needs res");
   const size_t nch = (size_t)M * (C / 8);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)y, scale, shift,
-                     (const bf16_t*)res, res_scale, res_shift, (bf16_t*)out, nch, C, 1, relu_mask);
+                     (const bf16_t*)res, res_scale, res_shift, (bf16_t*)out, nch, C, 1, relu_mask, g_ew_nt);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
@@ -1548,11 +1702,11 @@ extern "C" int yolo_bn_act_bwd_apply(const void* dout, const void* out, int relu
   if (dy2)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<PlainGrad, true>), dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, gp, (const bf16_t*)y, a1,
                        mean, rstd, k1, k2, (bf16_t*)dy, acc_dy, (const bf16_t*)y2, a2, mean2, rstd2, k1b, k2b, (bf16_t*)dy2, (bf16_t*)dres,
-                       acc_dres, (size_t)M, C);
+                       acc_dres, (size_t)M, C, g_ew_nt);
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<PlainGrad, false>), dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, gp, (const bf16_t*)y, a1,
                        mean, rstd, k1, k2, (bf16_t*)dy, acc_dy, (const bf16_t*)y2, a2, mean2, rstd2, k1b, k2b, (bf16_t*)dy2, (bf16_t*)dres,
-                       acc_dres, (size_t)M, C);
+                       acc_dres, (size_t)M, C, g_ew_nt);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
@@ -1711,7 +1865,7 @@ extern "C" int yolo_bn_pool_bwd_apply(const void* dout, const void* out, const u
   hipLaunchKernelGGL((bn_bwd_apply_kernel<PoolGrad, false>), dim3(ew_grid(M * (C / 8))), dim3(EW_THREADS), 0, (hipStream_t)stream, gp,
                      (const bf16_t*)y, a1, mean, rstd, k1, k2, (bf16_t*)dy, 0, (const bf16_t*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr,
-                     (bf16_t*)nullptr, 0, M, C);
+                     (bf16_t*)nullptr, 0, M, C, 0);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

@@ -201,7 +201,13 @@ class Graph(object):
         # its tile sums with integer atomics -- associative, so bit-reproducible -- into 16 buckets, and the unit's finalize + apply run as ONE
         # launch whatever the layer size (with partial ROWS that only pays below ~128 rows): the separate finalize launches (~5 us of
         # dependent-launch floor each, forward and backward) disappear for every plain conv -> BatchNorm unit.  YOLO_STAT_ACC=0 for A/B runs.
-        self.stat_acc = os.environ.get('YOLO_STAT_ACC', '1') != '0'
+        # Measured (profiles/HISTORY.md, round 3): the one-workgroup-per-CU merged launch wins below ~6 M elements (the 26 x 26 and 13 x 13 maps at
+        # batch 32: 8-9 us against 6.5 + 5.5); on larger tensors it is slower than finalize + the 8-workgroups-per-CU streaming apply, and the
+        # streaming kernels that derive their constants from the block themselves (yolo_set_tuning acc_stream_kelems) pay ~6 us of prologue --
+        # 2048 workgroups re-reading the same 16 KB of accumulator lines -- for the ~5.5 us launch they save.  YOLO_ACC_MAX_ELEMS caps the
+        # units that take the accumulator path.
+        self.stat_acc = os.environ.get('YOLO_STAT_ACC', '0') != '0'
+        self.acc_max_elems = int(float(os.environ.get('YOLO_ACC_MAX_ELEMS', '6e6')))
         self.acc_buf = None
         self.fin_merge_rows = int(os.environ.get('YOLO_FIN_MERGE_ROWS', '128'))
         self.fin_merge_bwd_rows = int(os.environ.get('YOLO_FIN_MERGE_BWD_ROWS', str(self.fin_merge_rows)))
@@ -910,14 +916,14 @@ class ApplyOp(object):
         on the other operand -- the merged finalize + apply launch then serves the unit at any size"""
         g, mb, m = self.g, self.m_bn, self.m_src
         if not (g.stat_acc and mb is not None and self.o_bn is None and m.kind == 'conv' and isinstance(mb, BNState) and len(mb.parts) == 1
-                and self.C % 32 == 0 and getattr(m, 'stats', None) is not None):
+                and self.C % 32 == 0 and getattr(m, 'stats', None) is not None and self.M * self.C <= g.acc_max_elems):
             return False
         return ops.conv2d_fwd_plan(m.p)['family'] != 'stem'
 
     def acc_bwd_eligible(self):
         """backward: the producer's epilogue leaves the unit's tile sums; one BatchNorm, the unit writes its own dy (no alias)"""
         mb = self.m_bn
-        if not (self.g.stat_acc and self.producer is not None):
+        if not (self.g.stat_acc and self.producer is not None and self.M * self.C <= self.g.acc_max_elems):
             return False
         y1, b1, y2, b2 = self._reduce_operands()
         return b2 is None and b1 is mb and isinstance(mb, BNState) and len(mb.parts) == 1 and self.C % 32 == 0 and not self.skip_dy
