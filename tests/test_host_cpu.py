@@ -81,14 +81,16 @@ def mocked_kernels(monkeypatch):
     return calls
 
 
+@pytest.mark.parametrize('acc', [False, True], ids=['rows', 'accumulators'])
 @pytest.mark.parametrize('backbone,n_conv,n_bn', [('resnet-18', 31, 28), ('resnet-18-v2', 31, 30), ('mixnet-18', 23, 52)])
-def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
+def test_graph_builder_names_and_plan(mocked_kernels, monkeypatch, backbone, n_conv, n_bn, acc):
     """layer counts of the reference's plot_model dumps (images/resnet-18.svg etc.) and Keras auto-names in the
     reference's construction order == the oracle's independent restatement"""
     from yolov3_tensorflow_amd.yolov3.yolov3_detector import YOLOv3Detector
     from yolov3_tensorflow_amd.yolov3.yolov3_loss import YOLOv3Loss
     from yolov3_tensorflow_amd.utils.radam import RAdam
     from oracle.nets import DetectorOracle
+    monkeypatch.setenv('YOLO_STAT_ACC', '1' if acc else '0')       # BatchNorm statistics through exact accumulators (off by default: measured slower)
     L = 5 + 13
     chans = [3 * L, 2 * L, 3 * L]
     m = YOLOv3Detector(backbone).build((96, 96, 3), chans, ['yolov3_head_8', 'yolov3_head_16', 'yolov3_head_32'], batch_size=2, device='cpu')
@@ -124,8 +126,12 @@ def test_graph_builder_names_and_plan(mocked_kernels, backbone, n_conv, n_bn):
     merged_b = c['bn_bwd_finalize_apply'] + c['bn_bwd_finalize_apply_acc']
     assert c['bn_finalize'] + merged_f + 4 * c['bn_finalize_grouped'] == n_bn      # MixNet: one grouped launch per 4 group BatchNorms
     assert merged_f + c['bn_act_fwd'] == len([op for op in m.g.tape if isinstance(op, engine.ApplyOp)])
-    assert c['bn_finalize_act_fwd_acc'] > 0 and c['bn_bwd_finalize_apply_acc'] > 0 and c['zero_words'] == 1
-    assert c['bn_finalize_act_fwd'] == 0 and c['bn_bwd_finalize_apply'] == 0        # (what the row-fed merged launch served, the accumulators serve too)
+    if acc:
+        assert c['bn_finalize_act_fwd_acc'] > 0 and c['bn_bwd_finalize_apply_acc'] > 0 and c['zero_words'] == 1
+        assert c['bn_finalize_act_fwd'] == 0 and c['bn_bwd_finalize_apply'] == 0    # (what the row-fed merged launch served, the accumulators serve too)
+    else:
+        assert c['bn_finalize_act_fwd'] > 0 and c['bn_bwd_finalize_apply'] > 0 and c['zero_words'] == 0
+        assert c['bn_finalize_act_fwd_acc'] == 0 and c['bn_bwd_finalize_apply_acc'] == 0
     assert merged_b + c['bn_act_bwd_apply'] <= merged_f + c['bn_act_fwd']
     if n_dw:
         assert c['dwconv_mix_fwd'] == 8 and c['dwconv_mix_dgrad'] == 8 and c['dwconv_mix_wgrad'] == 8

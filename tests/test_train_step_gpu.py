@@ -275,6 +275,41 @@ def test_relu_mask_switch_alone_keeps_the_relu_derivative(monkeypatch):
     assert rel_l2(grads[0], grads[1]) < 2e-2, rel_l2(grads[0], grads[1])
 
 
+def test_accumulator_statistics_plan_agrees(monkeypatch):
+    """YOLO_STAT_ACC=1 (BatchNorm statistics through exact int64 accumulators, finalize + apply in one launch for every plain conv -> BatchNorm
+    unit; off by default because it measured slower) against the default statistics-rows plan on the same weights and batch: the column
+    totals are the same numbers summed exactly instead of in double, so loss and gradients agree to rounding noise"""
+    H = W = 128
+    images, labels = make_batch(4, H, W, 6, 7, seed=9)
+    from yolov3_tensorflow_amd import engine
+    res = []
+    for acc in ('0', '1'):
+        monkeypatch.setenv('YOLO_STAT_ACC', acc)
+        model, loss, opt, grids = build('resnet-18', H, W, 4, 7, rect=-1)
+        units = [op for op in model.g.tape if isinstance(op, engine.ApplyOp)]
+        n_f = sum(getattr(op, 'acc_f', None) is not None for op in units)
+        n_b = sum(getattr(op, 'acc_b', None) is not None for op in units)
+        assert (n_f > 10 and n_b > 10 and model.g.acc_buf is not None) if acc == '1' else (n_f == 0 and n_b == 0 and model.g.acc_buf is None)
+        model.use_hip_graph = False
+        model.stage_batch(torch.from_numpy(images), torch.from_numpy(labels))
+        model.g.training = True
+        model._fwd_bwd()
+        torch.cuda.synchronize()
+        grad = model.g.ps.grad.detach().float().cpu().numpy().copy()
+        l0 = float(loss.total.item())
+        model.g.ps.grad.zero_()
+        losses = []
+        for _ in range(3):
+            model.run_step()
+            losses.append(float(model.loss_value.item()))
+        res.append((grad, l0, losses))
+        del model, loss, opt
+    (g0, a0, l0), (g1, a1, l1) = res
+    assert abs(a0 - a1) <= 2e-4 * abs(a0), (a0, a1)
+    assert rel_l2(g1, g0) < 2e-2, rel_l2(g1, g0)
+    assert abs(l1[0] - l0[0]) <= 2e-4 * abs(l0[0]) and abs(l1[2] - l0[2]) <= 4e-2 * abs(l0[2]), (l0, l1)
+
+
 def test_loss_curve_graph_replay():
     """6 training steps with hipGraph replay vs the float32 oracle, at the learning rate the reference's scheduler applies in
     its first epochs (1e-5, configs.py:16-17).  Steps 1-5 take RAdam's momentum branch, step 6 the adaptive one (rho_t >= 5).
