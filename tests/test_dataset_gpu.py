@@ -2,9 +2,13 @@
 Letterbox + x/255 + BGR and the salt-and-pepper decisions are bit-exact; gaussian noise (logf / cosf) and the contrast mean (summation
 order) agree to 3e-6 absolute on values in [0, 1].  TensorFlow itself is not available: see the oracle's header (parity unpinned
 against TF, Philox pinned against the Random123 known-answer vectors in the CPU suite)."""
+import os
+import time
 import numpy as np
 import pytest
 import torch
+
+t_start = time.time()
 
 pytestmark = pytest.mark.gpu
 
@@ -110,6 +114,38 @@ def test_get_dataset_yields_device_batches(tmp_path):
         np.testing.assert_array_equal(x[n].cpu().numpy(), ods.to_float_bgr(ods.letterbox(raw, (64, 64))))
         k = 1 + int(paths[n].split('/')[-1][0]) % 3
         assert (y[n].reshape(-1, 5)[:k, 4] == np.arange(k)).all() and (y[n].reshape(-1, 5)[k:] == -1).all()
+
+
+def test_process_pool_decode_yields_the_same_batches(tmp_path):
+    """FileUtil.get_dataset(decode_procs=2): the JPEG / PNG decode runs in two spawned worker processes that write into the shared,
+    page-locked staging slots; order, labels, augmentation draws and pixels are those of the thread path -- bit for bit"""
+    from PIL import Image
+    from yolov3_tensorflow_amd.dataset.file_util import FileUtil
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    rng = np.random.default_rng(1)
+    lines = []
+    for i in range(7):
+        Image.fromarray(rng.integers(0, 255, (40 + 5 * i, 64 - 3 * i, 3), dtype=np.uint8)).save(tmp_path / ('%d.png' % i))
+        lines.append('%d.png ' % i + ' '.join('0.5 0.5 0.2 0.2 %d' % j for j in range(1 + i % 3)))
+    (tmp_path / 'label.txt').write_text('\n'.join(lines) + '\n')
+    args = (str(tmp_path / 'label.txt'), str(tmp_path), (64, 64), 3)
+    a = FileUtil.get_dataset(*args, is_augment=True, is_test=False, num_workers=2)
+    b = FileUtil.get_dataset(*args, is_augment=True, is_test=False, decode_procs=2)
+    try:
+        for _ in range(6):                                     # crosses an epoch boundary (7 files, batches of 3)
+            (xa, ya), (xb, yb) = next(a), next(b)
+            assert torch.equal(xa, xb) and np.array_equal(ya, yb)
+    finally:
+        a.close()
+        b.close()
+    ta = list(FileUtil.get_dataset(*args, is_augment=False, is_test=True))
+    tb = list(FileUtil.get_dataset(*args, is_augment=False, is_test=True, decode_procs=2))
+    assert len(ta) == len(tb) == 3
+    for (xa, ya, pa), (xb, yb, pb) in zip(ta, tb):
+        assert torch.equal(xa, xb) and np.array_equal(ya, yb) and pa == pb
+    import glob
+    assert not [f for f in glob.glob('/dev/shm/psm_*') if os.path.getmtime(f) > t_start], 'shared staging segments must be unlinked'
 
 
 def test_augment_image_entry_point():

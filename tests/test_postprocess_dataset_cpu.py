@@ -206,3 +206,42 @@ def test_letterbox_matches_the_references_own_frames():
                 assert np.percentile(bar, 99) <= 24, (name, bar.shape)
         inside = ref[top + 2:top + nh - 2, left + 2:left + nw - 2]
         assert inside.mean() > 24, name                       # (and the content is not itself dark)
+
+
+def test_decode_worker_writes_into_a_shared_segment(tmp_path):
+    """the decode workers of FileUtil.get_dataset(decode_procs=...): header probe and decode-into-shared-memory (called in process here and
+    through the two-process pool the GPU path uses)"""
+    from multiprocessing import shared_memory
+    from PIL import Image
+    from yolov3_tensorflow_amd.dataset import decode_worker
+    rng = np.random.default_rng(3)
+    paths, imgs = [], []
+    for i, (h, w) in enumerate(((30, 44), (51, 20), (8, 8))):
+        im = rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+        p = str(tmp_path / ('%d.png' % i))
+        Image.fromarray(im).save(p)
+        paths.append(p)
+        imgs.append(im)
+    assert [decode_worker.probe_size(p) for p in paths] == [im.shape[:2] for im in imgs]
+    offs = np.cumsum([0] + [(im.size + 15) // 16 * 16 for im in imgs])
+    shm = shared_memory.SharedMemory(create=True, size=int(offs[-1]) + 64)
+    try:
+        tasks = [(shm.name, int(offs[i]), imgs[i].shape[0], imgs[i].shape[1], paths[i]) for i in range(3)]
+        pool = decode_worker.DecodePool(2)                     # two worker interpreters (python -m ...decode_worker), JSON lines over pipes
+        try:
+            assert pool.probe_sizes(paths) == [im.shape[:2] for im in imgs]
+            pool.submit(tasks[1:])
+            pool.submit([(shm.name, 0, 5, 5, paths[0])])         # planned size != decoded size
+            pool.wait_oldest()
+            with pytest.raises(RuntimeError, match='decodes to'):
+                pool.wait_oldest()                               # ... is loud, and the pool keeps working
+            pool.submit([tasks[0]])
+            pool.wait_oldest()
+        finally:
+            pool.close()
+        for i, im in enumerate(imgs):
+            got = np.ndarray(im.shape, np.uint8, buffer=shm.buf, offset=int(offs[i]))
+            np.testing.assert_array_equal(got, im)
+    finally:
+        shm.close()
+        shm.unlink()

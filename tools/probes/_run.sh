@@ -1,10 +1,5 @@
 set -o pipefail
 export TMPDIR=/tmp
-rm -f gpurun_out/r3h_bench.txt
-for i in 1 2 3; do
-  for t in 0 3 11 19 27; do
-    echo "== ew_nt=$t" >> gpurun_out/r3h_bench.txt
-    YOLO_TUNE=ew_nt=$t timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-roofline 2>gpurun_out/r3h_bench.err | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['final_loss'])" >> gpurun_out/r3h_bench.txt
-  done
-done
-cat gpurun_out/r3h_bench.txt
+timeout -k 10 400 python tools/input_pipeline_bench.py --real --images 640 --train --procs 16 12 --batches 100 > gpurun_out/r3i_pipe_train_real.txt 2>&1; echo "rc=$?"; grep -v amdgpu.ids gpurun_out/r3i_pipe_train_real.txt | tail -5
+timeout -k 10 400 python tools/input_pipeline_bench.py --real --images 640 --procs 16 --workers 8 --batches 100 > gpurun_out/r3i_pipe_real.txt 2>&1; echo "rc=$?"; grep -v amdgpu.ids gpurun_out/r3i_pipe_real.txt
+python -m pytest tests/test_trainer_e2e_gpu.py tests/test_config1_gpu.py tests/test_reference_default_run_gpu.py -x -q > gpurun_out/r3i_tests2.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r3i_tests2.log

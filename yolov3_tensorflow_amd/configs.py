@@ -69,6 +69,10 @@ DEFAULTS = dict(
     gpu_num=1,
     visible_gpu='0',
     full_state_resume=False,
+    # (not in the reference) JPEG decode of the training set on this many worker PROCESSES that write into shared page-locked staging memory
+    # (dataset/decode_worker.py; the reference's tf.data pipeline decodes with AUTOTUNE parallelism, dataset/file_util.py:80-88).
+    # 0 = decode on Python threads (~2000-3000 images/s: the interpreter parts of PIL serialise)
+    decode_procs=12,
 )
 
 FLAGS = AttrDict()

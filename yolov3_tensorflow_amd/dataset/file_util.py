@@ -18,6 +18,7 @@ class _Slot(object):
     """one in-flight batch: pinned staging bytes + descriptor block, their device twins, and the event after which they may be reused"""
 
     def __init__(self):
+        self.shm = None                               # shared-memory segment behind ``stage`` (process-pool decode), else None
         self.stage = self.dev = self.desc_host = self.desc_dev = self.event = None
         self.descs = self.total = self.views = None
         self.uploaded = self.alloc_stream = None      # upload-finished event; the stream the device buffers were allocated on (until first use)
@@ -28,7 +29,7 @@ class DeviceImagePipeline(object):
     bf16 conv input).  Batches travel through a ring of slots (pinned staging buffer + descriptor block + device twins): decode threads
     write their pixels straight into the pinned buffer of a slot while the GPU still works on the previous ones."""
 
-    def __init__(self, batch_size, image_size, device=None, max_pixels_per_image=4096 * 4096, slots=4):
+    def __init__(self, batch_size, image_size, device=None, max_pixels_per_image=4096 * 4096, slots=4, shared=False):
         import torch
         from yolov3_tensorflow_amd import ops, _lib
         if not torch.cuda.is_available():
@@ -41,6 +42,48 @@ class DeviceImagePipeline(object):
         self._slots = [_Slot() for _ in range(max(2, int(slots)))]
         self._copy_stream = None
         self._next = 0
+        # shared: the staging buffers are POSIX shared-memory segments that decode PROCESSES attach to by name (decode_worker.py), page-locked
+        # in this process with hipHostRegister so that the upload stays an asynchronous DMA
+        self.shared = bool(shared)
+        if self.shared:
+            import weakref
+            weakref.finalize(self, DeviceImagePipeline._release, self._slots, torch)
+
+    @staticmethod
+    def _release(slots, torch):
+        for slot in slots:
+            if slot.shm is not None:
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(slot.stage.data_ptr())
+                except Exception:
+                    pass
+                slot.stage = None
+                try:
+                    slot.shm.close()
+                    slot.shm.unlink()
+                except Exception:
+                    pass
+                slot.shm = None
+
+    def close(self):
+        """unmap and unlink the shared staging segments (they live in /dev/shm until then)"""
+        if self.shared:
+            self.torch.cuda.synchronize(self.device)
+            DeviceImagePipeline._release(self._slots, self.torch)
+
+    def _alloc_stage(self, slot, nbytes):
+        torch = self.torch
+        if not self.shared:
+            slot.stage = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            return
+        from multiprocessing import shared_memory
+        if slot.shm is not None:
+            DeviceImagePipeline._release([slot], torch)
+        slot.shm = shared_memory.SharedMemory(create=True, size=nbytes)
+        slot.stage = torch.frombuffer(slot.shm.buf, dtype=torch.uint8, count=nbytes)
+        err = torch.cuda.cudart().cudaHostRegister(slot.stage.data_ptr(), nbytes, 0)
+        if int(err) != 0:
+            raise RuntimeError('hipHostRegister of the shared staging buffer failed (%s)' % err)
 
     @staticmethod
     def geometry(h, w, H, W):
@@ -73,7 +116,7 @@ class DeviceImagePipeline(object):
             total += (h * w * 3 + 15) // 16 * 16
         if slot.stage is None or slot.stage.numel() < total:
             with torch.cuda.device(self.device):
-                slot.stage = torch.empty(int(total * 1.25), dtype=torch.uint8).pin_memory()
+                self._alloc_stage(slot, int(total * 1.25))
                 slot.dev = torch.empty(slot.stage.numel(), dtype=torch.uint8, device=self.device)
                 slot.alloc_stream = torch.cuda.current_stream(self.device)
                 if slot.desc_host is None:
@@ -81,6 +124,7 @@ class DeviceImagePipeline(object):
                     slot.desc_dev = torch.empty_like(slot.desc_host, device=self.device)
         stage = slot.stage.numpy()
         slot.descs, slot.total = descs, total
+        slot.offsets = [int(descs[n].offset) for n in range(self.N)]
         slot.views = [stage[descs[n].offset:descs[n].offset + descs[n].h * descs[n].w * 3].reshape(descs[n].h, descs[n].w, 3)
                       for n in range(self.N)]
         return slot
@@ -164,7 +208,7 @@ class FileUtil(object):
 
     @staticmethod
     def host_batches(file_path, image_dir, image_size, batch_size, is_augment=True, is_test=False, seed=800, pool=None, pipe=None,
-                     rank=0, world=1):
+                     rank=0, world=1, sizes=None):
         """the host half of get_dataset: (decoded images, padded transformed labels (N, T*5), augmentation draws or None, paths).
         ``pool``: a concurrent.futures executor that decodes the images of a batch in parallel (PIL releases the GIL while decoding);
         order, pairing and the random draws do not depend on it.  With ``pipe`` (a DeviceImagePipeline) the first element is a filled slot
@@ -199,13 +243,16 @@ class FileUtil(object):
                 labs = -np.ones((batch_size, t_max, 5), dtype=np.float32)
                 paths = [os.path.join(image_dir, names[j]) for j in idx]
                 mapper = pool.map if pool is not None else map
-                imgs = list(mapper(FileUtil.read_image, paths))
-                sizes = [im.shape[:2] for im in imgs]
-                if pipe is not None:                                 # into the pinned staging memory, also on the decode threads
-                    arrays, imgs = imgs, pipe.acquire(sizes)
-                    list(mapper(FileUtil._copy_into, zip(imgs.views, arrays)))
+                if sizes is not None:                                # planning only (process-pool decode): {path: (h, w)} from the file headers
+                    imgs, shapes = None, [sizes[p] for p in paths]
+                else:
+                    imgs = list(mapper(FileUtil.read_image, paths))
+                    shapes = [im.shape[:2] for im in imgs]
+                    if pipe is not None:                             # into the pinned staging memory, also on the decode threads
+                        arrays, imgs = imgs, pipe.acquire(shapes)
+                        list(mapper(FileUtil._copy_into, zip(imgs.views, arrays)))
                 for k, j in enumerate(idx):
-                    lb = FileUtil.transform_label(labels[j], sizes[k], image_size)
+                    lb = FileUtil.transform_label(labels[j], shapes[k], image_size)
                     labs[k, :len(lb)] = lb
                 yield imgs, labs.reshape(batch_size, t_max * 5), draws, paths
             if is_test:
@@ -213,7 +260,7 @@ class FileUtil(object):
 
     @staticmethod
     def get_dataset(file_path, image_dir, image_size, batch_size, is_augment=True, is_test=False, seed=800, device=None, num_workers=None,
-                    prefetch=3, rank=None, world=None):
+                    prefetch=3, rank=None, world=None, decode_procs=None):
         """reference :62-114 (its tf.data pipeline decodes with AUTOTUNE parallelism and prefetches, :85-114).  Here ``num_workers`` threads
         (default: the CPUs of this process, at most 8 -- Python threads stop scaling there: ~3000 images/s of 500 x 375 JPEGs on the GPU box's host,
         tools/input_pipeline_bench.py) decode the JPEGs of a batch and a producer thread keeps ``prefetch`` decoded
@@ -223,6 +270,11 @@ class FileUtil(object):
         import concurrent.futures
         import queue
         import threading
+        if decode_procs is None:
+            decode_procs = int(os.environ.get('YOLO_DECODE_PROCS', '0'))
+        if decode_procs and decode_procs > 0:
+            return FileUtil._get_dataset_procs(file_path, image_dir, image_size, batch_size, is_augment, is_test, seed, device, int(decode_procs),
+                                               max(2, prefetch), rank, world)
         pipe = DeviceImagePipeline(batch_size, image_size, device=device, slots=max(1, prefetch) + 3)
         if world is None:
             world = 1 if is_test else int(os.environ.get('WORLD_SIZE', '1'))
@@ -269,4 +321,49 @@ class FileUtil(object):
                 stop.set()
                 if pool is not None:
                     pool.shutdown(wait=False)
+        return batches()
+
+    @staticmethod
+    def _get_dataset_procs(file_path, image_dir, image_size, batch_size, is_augment, is_test, seed, device, procs, window, rank, world):
+        """get_dataset with the JPEG decode on ``procs`` worker PROCESSES (decode_worker.DecodePool: separate interpreters that import PIL and
+        NumPy only and never touch the GPU).  The parent plans every batch -- order, labels, augmentation draws, and from the files' header
+        sizes the byte offset of every image in a staging slot -- and hands out (segment, offset, size, path) tasks; the workers write the
+        decoded pixels directly into the slot's shared, page-locked memory.  ``window`` batches are in flight at the pool while the consumer
+        uploads and launches the previous ones: same batches, same order, same draws as the thread path (host_batches plans both)."""
+        from yolov3_tensorflow_amd.dataset import decode_worker
+        if world is None:
+            world = 1 if is_test else int(os.environ.get('WORLD_SIZE', '1'))
+        if rank is None:
+            rank = 0 if is_test else int(os.environ.get('RANK', '0'))
+        pipe = DeviceImagePipeline(batch_size, image_size, device=device, slots=window + 3, shared=True)
+        pool = decode_worker.DecodePool(procs)
+        names, _ = FileUtil._parse_label_file(file_path)
+        paths_all = sorted(set(os.path.join(image_dir, n) for n in names))
+        sizes = dict(zip(paths_all, pool.probe_sizes(paths_all)))
+
+        def batches():
+            inflight = []
+            planner = FileUtil.host_batches(file_path, image_dir, image_size, batch_size, is_augment, is_test, seed, pool=None, pipe=None,
+                                            rank=rank, world=world, sizes=sizes)           # plans only: it needs the sizes, not the pixels
+            exhausted = False
+            try:
+                while True:
+                    while not exhausted and len(inflight) < window:
+                        try:
+                            _, labs, draws, paths = next(planner)
+                        except StopIteration:
+                            exhausted = True
+                            break
+                        slot = pipe.acquire([sizes[p] for p in paths])
+                        pool.submit([(slot.shm.name, off, sizes[p][0], sizes[p][1], p) for off, p in zip(slot.offsets, paths)])
+                        inflight.append((slot, labs, draws, paths))
+                    if not inflight:
+                        return
+                    slot, labs, draws, paths = inflight.pop(0)
+                    pool.wait_oldest()                           # (re-raises a worker's exception here)
+                    x = pipe.run(slot, draws)
+                    yield (x, labs, paths) if is_test else (x, labs)
+            finally:
+                pool.close()
+                pipe.close()
         return batches()

@@ -22,7 +22,8 @@ def train(yolov3_trainer):
     logging.info('loading training set: %s', FLAGS.train_label_path)
     # FLAGS.batch_size is the global batch; under torchrun every rank reads its slice of it (FileUtil.host_batches)
     train_dataset = FileUtil.get_dataset(FLAGS.train_label_path, FLAGS.train_set_dir, image_size=FLAGS.input_image_size[0:2],
-                                         batch_size=yolov3_trainer.batch_size, is_augment=FLAGS.is_augment, is_test=False)
+                                         batch_size=yolov3_trainer.batch_size, is_augment=FLAGS.is_augment, is_test=False,
+                                         decode_procs=FLAGS.get('decode_procs'))
     # (the trainer's defaults for these two are bound when its module is imported, as in the reference, trainer.py:99; FLAGS edited after that
     #  import are honoured by passing the current values)
     yolov3_trainer.train(train_dataset, None, train_steps=FLAGS.steps_per_epoch, val_steps=FLAGS.validation_steps)

@@ -111,7 +111,9 @@ class YOLOv3Trainer(object):
             losses = []
             for _ in range(train_steps):
                 images, labels = next(it)
-                losses.append(self.model.train_on_batch(images, labels))
+                losses.append(self.model.train_on_batch(images, labels, sync=False))     # device scalars: one synchronisation per epoch
+            import torch
+            losses = torch.stack(losses).double().cpu().numpy()
             # keras reports the running mean over the epoch; data parallel: the mean over the ranks' shards, the same number everywhere
             epoch_loss = parallel.agree_mean(float(np.mean(losses)), self.model.device, self.model.process_group)
             failure = None

@@ -70,8 +70,23 @@ class YOLOv3Loss(object):
                 self._alloc(self.dev, self.N, self.ldc, int(lab.shape[1]))
             if self.model is not None:
                 self.model._graphs = None
-        self.labels.fill_(-1.0)
-        self.labels[:, :lab.shape[1]].copy_(lab.to(torch.float32), non_blocking=True)
+        if torch.is_tensor(lab) and lab.is_cuda:       # already on the device: a device-side copy
+            self.labels.fill_(-1.0)
+            self.labels[:, :lab.shape[1]].copy_(lab.to(torch.float32), non_blocking=True)
+            return
+        # through a ring of page-locked buffers: a copy from pageable host memory is synchronous on this runtime -- it waits for everything
+        # queued on the stream, i.e. for the previous training step -- and made every file-fed step pay a device synchronisation
+        ring = getattr(self, '_lab_ring', None)
+        if ring is None or ring[0][0].shape != self.labels.shape:
+            ring = self._lab_ring = [(torch.empty(self.labels.shape, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+            self._lab_next = 0
+        pin, ev = ring[self._lab_next]
+        self._lab_next = (self._lab_next + 1) % len(ring)
+        ev.synchronize()                               # (the upload that last used this buffer, four batches ago)
+        pin.fill_(-1.0)
+        pin[:, :lab.shape[1]].copy_(torch.as_tensor(lab, dtype=torch.float32))
+        self.labels.copy_(pin, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.dev))
 
     def launch(self, model):
         """enqueue loss forward+backward for the model's current head logits; d(logits) lands in the heads' dy buffers"""
