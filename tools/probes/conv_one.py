@@ -31,8 +31,8 @@ fl = 2.0 * N * H * W * Cout * Cin * 9
 
 
 def apply(setting):
-    for k in ('pstrip', 'strip_bm', 'ps_depth'):
-        ops.set_tuning(k, {'pstrip': -1, 'strip_bm': -1, 'ps_depth': 3}[k])
+    for k in ('pstrip', 'strip_bm', 'ps_depth', 'stream'):
+        ops.set_tuning(k, {'pstrip': 0, 'strip_bm': -1, 'ps_depth': 3, 'stream': -1}[k])
     for kv in filter(None, setting.split(',')):
         k, v = kv.split('=')
         ops.set_tuning(k, int(v))

@@ -62,6 +62,13 @@ int yolo_pstrip_plan(const yoloconv::Gather& g, int Kout, bool f32, PsPlanOut* o
 int yolo_pstrip_launch(const yoloconv::Gather& g, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st);
 extern int g_pstrip, g_ps_depth;      // "pstrip" tuning: -1 auto, 0 never, 1 + v = force variant v
 
+// ---- weights-in-registers streaming kernel of the 64-channel 3x3 / stride-1 layers (conv_stream.hip), dispatched from conv_igemm.hip ----
+struct StreamPlanOut { int span, nx, ny; size_t lds; };
+// 0 = the streaming kernel does not take this problem, else the pixels per workgroup (statistics / partial rows = ceil(M / that))
+int yolo_stream_plan(const yoloconv::Gather& g, int Kout, bool f32, StreamPlanOut* out);
+int yolo_stream_launch(const yoloconv::Gather& g, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st);
+extern int g_stream;                  // "stream" tuning: -1 auto, 0 never, 1 wherever it fits
+
 namespace {
 using yoloconv::Gather; using yoloconv::ClassView; using yoloconv::BnEpi; using yoloconv::Epi;
 

@@ -1037,6 +1037,7 @@ int pick_strip(const Gather& g, int Kout, bool f32, int* bnp = nullptr) {
   return bm;
 }
 int stat_rows_for(const Gather& g, int Kout) {
+  if (const int sp = yolo_stream_plan(g, Kout, false, nullptr)) return (g.M + sp - 1) / sp;
   if (const int pb = yolo_pstrip_plan(g, Kout, false, nullptr)) return (g.M + pb - 1) / pb;
   const int sb = pick_strip(g, Kout, false);
   if (sb) return (g.M + sb - 1) / sb;
@@ -1143,6 +1144,7 @@ int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int l
                int Kout, hipStream_t st) {
   int sbn = 0;
   if constexpr (!F32) {
+    if (!bias && accumulate != 2 && yolo_stream_plan(g, Kout, false, nullptr)) return yolo_stream_launch(g, w, y, ldy, accumulate, e, Kout, st);
     if (!bias && yolo_pstrip_plan(g, Kout, false, nullptr)) return yolo_pstrip_launch(g, w, y, ldy, accumulate, e, Kout, st);
   }
   if (const int sb = pick_strip(g, Kout, F32, &sbn)) {
@@ -1189,6 +1191,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "ps_depth")) { YOLO_CHECK_ARG(value == 1 || value == 3, "ps_depth"); g_ps_depth = value; }
   else if (!strcmp(name, "ew_nt")) { YOLO_CHECK_ARG(value >= 0 && value <= 3, "ew_nt"); g_ew_nt = value; }
   else if (!strcmp(name, "acc_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "acc_stream_kelems"); g_acc_stream_elems = (int64_t)value * 1000; }
+  else if (!strcmp(name, "stream")) { YOLO_CHECK_ARG(value >= -1 && value <= 1, "stream"); g_stream = value; }
   else if (!strcmp(name, "pstrip")) { YOLO_CHECK_ARG(value >= -1 && value <= 4, "pstrip"); g_pstrip = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
@@ -1211,6 +1214,11 @@ extern "C" int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info) {
   if (yolo_stem_applies(p)) { info[0] = 3; info[4] = yolo_stem_stat_rows(p); return YOLO_OK; }
   static const char dummy = 0;
   const Gather g = fwd_gather(p, &dummy, &dummy);
+  StreamPlanOut sp;
+  if (yolo_stream_plan(g, p->Cout, false, &sp)) {
+    info[0] = 4; info[1] = 64; info[2] = 64; info[3] = sp.span; info[4] = sp.nx * sp.ny; info[5] = (int32_t)sp.lds;
+    return YOLO_OK;
+  }
   PsPlanOut pl;
   if (yolo_pstrip_plan(g, p->Cout, false, &pl)) {
     info[0] = 2; info[1] = pl.bm; info[2] = pl.bn; info[3] = pl.tstride; info[4] = pl.tiles; info[5] = (int32_t)pl.lds; info[6] = pl.ring;

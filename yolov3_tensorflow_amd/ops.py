@@ -62,7 +62,7 @@ def conv2d_stat_rows(p):
     return r
 
 
-CONV_FAMILIES = ('igemm', 'strip', 'pstrip', 'stem')
+CONV_FAMILIES = ('igemm', 'strip', 'pstrip', 'stem', 'stream')
 
 
 def conv2d_fwd_plan(p):
