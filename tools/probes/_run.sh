@@ -1,8 +1,11 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_stream_gpu.py -x -q > gpurun_out/r3e_stream_tests.txt 2>&1
-echo "tests rc=$?" 
-tail -5 gpurun_out/r3e_stream_tests.txt
-timeout -k 10 300 python tools/probes/conv_one.py 32 104 104 64 64 "stream=0" "stream=1" > gpurun_out/r3e_stream_time.txt 2>&1
-timeout -k 10 300 python tools/probes/conv_one.py 32 104 104 64 64 "stream=0" "stream=1" --dgrad >> gpurun_out/r3e_stream_time.txt 2>&1
-cat gpurun_out/r3e_stream_time.txt
+: > gpurun_out/r3e_bench_ab.txt
+for i in 1 2; do
+for t in "stream=0" "stream=-1"; do
+  echo "== $t" >> gpurun_out/r3e_bench_ab.txt
+  YOLO_TUNE=$t timeout -k 10 300 python bench.py --steps 60 --warmup 15 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])" >> gpurun_out/r3e_bench_ab.txt || exit 1
+done; done
+cat gpurun_out/r3e_bench_ab.txt

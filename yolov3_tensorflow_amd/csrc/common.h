@@ -11,12 +11,15 @@ typedef uint16_t bf16_t;  // storage type of one element
 #ifdef YOLO_FP16
 typedef _Float16 bf16x8_t __attribute__((ext_vector_type(8)));
 #define YOLO_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define YOLO_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #else
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #define YOLO_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define YOLO_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #endif
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 #define YOLO_WAVE 64
 

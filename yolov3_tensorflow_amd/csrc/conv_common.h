@@ -26,6 +26,7 @@ struct Gather {
   // ---- stride-2 data gradient as 4 parity classes (blockIdx.y = 2 * (h & 1) + (w & 1) of the output pixel): each class is a dense
   // stride-1 correlation over dY with 1 or 2 of the 3 taps per dimension, written to every other row / column of dX; the kernel
   // specialises its copy of this struct per class (s2 == 0: everything below is unused)
+  int role;            // 0 = forward launch, 1 = data gradient (kernel selection only: the data gradient runs beside the weight-gradient stream)
   int s2;
   int s2_ny;           // classes launched (grid y): 4, or 1 = only the even / even class (1x1 stride-2: the other positions get nothing)
   int N, S_full;       // images; tap columns of the (flipped) weight tensor
@@ -67,7 +68,7 @@ struct StreamPlanOut { int span, nx, ny; size_t lds; };
 // 0 = the streaming kernel does not take this problem, else the pixels per workgroup (statistics / partial rows = ceil(M / that))
 int yolo_stream_plan(const yoloconv::Gather& g, int Kout, bool f32, StreamPlanOut* out);
 int yolo_stream_launch(const yoloconv::Gather& g, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st);
-extern int g_stream;                  // "stream" tuning: -1 auto, 0 never, 1 wherever it fits
+extern int g_stream;                  // "stream" tuning (conv_stream.hip)
 
 namespace {
 using yoloconv::Gather; using yoloconv::ClassView; using yoloconv::BnEpi; using yoloconv::Epi;

@@ -987,6 +987,7 @@ Gather fwd_gather(const yolo_conv_problem* p, const void* src0, const void* src1
   g.smul = p->stride; g.pad_h = p->pad_t; g.pad_w = p->pad_l; g.den = 1;
   g.M = p->N * p->Ho * p->Wo; g.Kg = p->R * p->S * p->Cin;
   g.rhw = 1.0f / (float)(g.Ho * g.Wo); g.rw = 1.0f / (float)g.Wo; g.magicS = 65536 / g.S + 1;
+  g.role = 0;
   g.s2 = 0; g.N = p->N; g.S_full = p->S; g.wKg = g.Kg; g.OH = p->Ho; g.OW = p->Wo;
   return g;
 }
@@ -1191,7 +1192,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "ps_depth")) { YOLO_CHECK_ARG(value == 1 || value == 3, "ps_depth"); g_ps_depth = value; }
   else if (!strcmp(name, "ew_nt")) { YOLO_CHECK_ARG(value >= 0 && value <= 3, "ew_nt"); g_ew_nt = value; }
   else if (!strcmp(name, "acc_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "acc_stream_kelems"); g_acc_stream_elems = (int64_t)value * 1000; }
-  else if (!strcmp(name, "stream")) { YOLO_CHECK_ARG(value >= -1 && value <= 1, "stream"); g_stream = value; }
+  else if (!strcmp(name, "stream")) { YOLO_CHECK_ARG(value >= -1 && value <= 2, "stream"); g_stream = value; }
   else if (!strcmp(name, "pstrip")) { YOLO_CHECK_ARG(value >= -1 && value <= 4, "pstrip"); g_pstrip = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
@@ -1281,6 +1282,7 @@ int dgrad_gather(const yolo_conv_problem* p, const void* dy, Gather* gp, bool ev
   g.smul = 1; g.pad_h = p->R - 1 - p->pad_t; g.pad_w = p->S - 1 - p->pad_l; g.den = p->stride;
   g.M = p->N * p->H * p->W; g.Kg = p->R * p->S * p->Cout;
   g.rhw = 1.0f / (float)(g.Ho * g.Wo); g.rw = 1.0f / (float)g.Wo; g.magicS = 65536 / g.S + 1;
+  g.role = 1;
   g.s2 = 0; g.s2_ny = 4; g.N = p->N; g.S_full = p->S; g.wKg = g.Kg; g.OH = p->H; g.OW = p->W;
   YOLO_CHECK_ARG(g.M < (1 << 24), "row decode needs N*H*W < 2^24");
   const bool k3 = p->R == 3 && p->S == 3;

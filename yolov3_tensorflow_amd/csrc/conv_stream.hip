@@ -21,26 +21,50 @@
 #include "conv_common.h"
 
 namespace {
+// Diagnostic builds only (make EXTRA_conv_stream=-DST_STAMPS; tools/probes/stream_stamps.py): s_memtime stamps of wave 0 of every workgroup.
+// In the product build no stamp executes and yolo_debug_st_stamps does not exist.
+#ifdef ST_STAMPS
+__device__ unsigned long long* g_st_stamps = nullptr;
+#define ST_STAMP(i)                                                                                      \
+  do {                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    unsigned long long t_;                                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (g_st_stamps && threadIdx.x == 0) g_st_stamps[blockIdx.x * 64 + (i)] = t_;                        \
+  } while (0)
+#else
+#define ST_STAMP(i) do {} while (0)
+#endif
 
 struct StreamArgs {
   const bf16_t* src; unsigned src_bytes;   // NHWC activations (or dY for the data gradient), C = 64
   const bf16_t* wt;  unsigned wt_bytes;    // [Kout][9][64]
   int H, W, M;                             // M = N*H*W
-  int span, ny;                            // pixels per workgroup (multiple of 64), channel tiles (Kout / 64)
-  int e0;                                  // 128 + roundup8(W + 1): the ring is filled up to pixel P0 + e0 before the first step
+  int span, ny;                            // pixels per workgroup (multiple of 128), channel tiles (Kout / 64)
+  int e0;                                  // 256 + roundup8(W + 1): the ring is filled up to pixel P0 + e0 before the first step
   float rhw, rw;
 };
 
-constexpr int ST_RING = 512;                         // ring rows
-constexpr int ST_ZERO = ST_RING * 128;               // 128 zero bytes
-constexpr int ST_WT = ST_ZERO + 128;                 // weight image: 9 taps x [64 channels][64 k] swizzled (72 KiB), dead after the prologue
-constexpr int ST_OLD = 144;                          // staged output row stride (128 + 16: conflict-free 16-byte writes)
-constexpr int ST_STAGE = ST_WT;                      // 2 staged tiles of 64 x 144 bytes (alias the weight image)
-constexpr int ST_RED = ST_WT + 2 * 64 * ST_OLD;      // final reduction: 3 x [8][64] floats
-constexpr int ST_LDS = ST_WT + 9 * 8192;
+constexpr int ST_ROWS = 896;                         // ring rows (a multiple of the 16-row swizzle period)
+constexpr int ST_RING_BYTES = ST_ROWS * 128;         // 112 KiB
+constexpr int ST_STEP = 128;                         // pixels per step
+constexpr int ST_ZERO = ST_RING_BYTES;               // 128 zero bytes
+constexpr int ST_OLD = 144;                          // staged output row stride (128 + 16)
+constexpr int ST_STAGE = ST_ZERO + 128;              // 2 staged tiles of 128 x 144 bytes
+constexpr int ST_LDS = 160 * 1024;
+constexpr int ST_WT = ST_LDS - 9 * 8192;             // weight image (prologue only): over the ring's last rows, the zero row and the staged tiles
+static_assert(ST_STAGE + 2 * ST_STEP * ST_OLD <= ST_LDS, "LDS budget");
 
+#ifndef ST_PHASED
+#define ST_PHASED 1
+#endif
 typedef unsigned st_v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x8_t st_lds_frag_t;
+
+// row swizzle of the [rows][64 bf16] images read by the 32x32x16 operand loads (32 consecutive rows, one 16-byte chunk each): the chunk index
+// is XOR-ed with bits 1-3 of the row -- conflict-free for ds_read_b128's lane groups at every row alignment
+__device__ __forceinline__ int st_sw(int row) { return (row >> 1) & 7; }
 
 // EPI: 0 = plain (forward: statistics of the stored values; plain data gradient), 1 = fused BatchNorm-backward reduce, 2 = the same with a
 // second (shortcut) BatchNorm.  ACC: the output is added to `addend` (or to the output buffer itself).  The hot loop is ONE basic block:
@@ -57,58 +81,63 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
   const int n0 = tile_n * 64;
   const int P0 = wg_m * a.span;
   const int P1 = min(P0 + a.span, a.M);
-  const int niter = (P1 - P0 + 63) >> 6;
-  if (tid < 8) *reinterpret_cast<uint4*>(smem + ST_ZERO + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  const int niter = (P1 - P0 + ST_STEP - 1) / ST_STEP;
+  const int Pbase = ((P0 - a.W - 1 + 1024) / 8 - 128) * 8;       // ring row 0 = pixel 8 * floor((P0 - W - 1) / 8): every pixel the range needs is >= it
+  ST_STAMP(0);
 
-  // ---- prologue: ring pieces [P0 - (W+1), P0 + e0) and the weight image -------------------------------------------------------
+  // ---- prologue: ring pieces [Pbase, P0 + e0) and the weight image ---------------------------------------------------------------
+  // LDS-DMA lane geometry: a piece is 8 rows x 128 bytes; lane -> row lane >> 3, 16-byte slot lane & 7, which holds chunk slot ^ st_sw(row);
+  // for row 8k + lrow that is 4 (k & 1) + (lrow >> 1)
   const int lrow = lane >> 3;
-  const int cchunk = (lane & 7) ^ lrow;
-  const int lane_src = lrow * 128 + cchunk * 16;                  // byte offset of this lane inside an 8-pixel piece of the source
+  auto lane_src = [&](int parity) { return lrow * 128 + (((lane & 7) ^ (4 * parity + (lrow >> 1))) << 4); };
+  const int K0 = (P0 + a.e0 - Pbase) >> 3;                        // pieces before the first step (< 96: they do not wrap)
   {
-    const int j_first = (P0 - a.W - 1 + 1024) / 8 - 128;          // floor((P0 - W - 1) / 8)
-    const int j_end = (P0 + a.e0) >> 3;
-    for (int j = j_first + wave; j < j_end; j += 8)
-      buffer_load_lds16(a.src, a.src_bytes, smem + ((j * 8) & (ST_RING - 1)) * 128, (unsigned)(j * 1024 + lane_src));
-    const unsigned wrow = (unsigned)(((n0 + wave * 8 + lrow) * 576 + cchunk * 8) * 2);
+    const int ls = lane_src(wave & 1);
+    for (int k = wave; k < K0; k += 8)
+      buffer_load_lds16(a.src, a.src_bytes, smem + k * 1024, (unsigned)((Pbase + 8 * k) * 128 + ls));
+    // weight image: row R = 32 h + r of tap t holds channel n0 + 32 h + perm(r) -- MFMA row r of the half-h waves (perm: see the accumulators)
+    const int R = wave * 8 + lrow, r = R & 31;
+    const int ch = n0 + (R & 32) + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+    const unsigned wrow = (unsigned)((ch * 576 + ((lane & 7) ^ st_sw(R)) * 8) * 2);
 #pragma unroll
     for (int t = 0; t < 9; ++t) buffer_load_lds16(a.wt, a.wt_bytes, smem + ST_WT + t * 8192 + wave * 1024, wrow + t * 128);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  ST_STAMP(1);
 
-  const int kq = lane >> 4;
-  bf16x8_t wreg[2][18];
+  const int kh = lane >> 5;                                       // k half of the 32x32x16 operand layout: 8 channels 8 kh .. +7 of a 16-channel substep
+  bf16x8_t wreg[36];
   {
-    const int r = lane & 15;
+    const int R = nh * 32 + (lane & 31);
 #pragma unroll
-    for (int cf = 0; cf < 2; ++cf) {
-      const int chl = nh * 32 + 8 * (r >> 2) + 4 * cf + (r & 3);   // MFMA row r of chain cf: so that a lane ends up with 8 consecutive channels
-#pragma unroll
-      for (int ks = 0; ks < 18; ++ks)
-        wreg[cf][ks] = *reinterpret_cast<const bf16x8_t*>(smem + ST_WT + (ks >> 1) * 8192 + swz(chl, (ks & 1) * 4 + kq));
-    }
+    for (int s_ = 0; s_ < 36; ++s_)
+      wreg[s_] = *reinterpret_cast<const bf16x8_t*>(smem + ST_WT + (s_ >> 2) * 8192 + R * 128 + (((2 * (s_ & 3) + kh) ^ st_sw(R)) << 4));
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();                                                // the weight image is dead: its space now stages the output tiles
+  __syncthreads();                                                // the weight image is dead
+  // the zero row; and zeros in the staged tiles, so that step 0's store side (nothing staged yet, offsets out of range) adds zeros to the sums
+  for (int o = tid * 16; o < 128 + 2 * ST_STEP * ST_OLD; o += 512 * 16) *reinterpret_cast<uint4*>(smem + ST_ZERO + o) = make_uint4(0u, 0u, 0u, 0u);
+  ST_STAMP(2);
 
-  // ---- per-lane state of the compute side: pixel P0 + 64 it + 16 mi + (lane & 15) ------------------------------------------------
-  int px = P0 + 16 * mi + (lane & 15);
+  // ---- per-lane state of the compute side: pixel P0 + 128 it + 32 mi + (lane & 31) -----------------------------------------------
+  int px = P0 + 32 * mi + (lane & 31);
   int py_, px_;                                                   // (row, column) of that pixel inside its image
   {
     int n_, rem;
     fast_divmod(px, a.H * a.W, a.rhw, n_, rem);
     fast_divmod(rem, a.W, a.rw, py_, px_);
   }
-  const int zero_addr = ST_ZERO + kq * 16;
-  const int stage_wr = ST_STAGE + (16 * mi + (lane & 15)) * ST_OLD + (nh * 32 + 8 * kq) * 2;
-  int tad[9];                                                     // unmasked LDS address of this lane's fragment row of tap t (k chunk kq)
+  const int zero_addr = ST_ZERO + kh * 16;
+  const int stage_wr = ST_STAGE + (32 * mi + (lane & 31)) * ST_OLD + nh * 64 + kh * 32;
+  unsigned tad[9];                                                // unmasked LDS address of this lane's row of tap t, chunk kh (substep s: ^ (s << 5))
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const int row = (px + (t / 3) * a.W + (t % 3) - a.W - 1) & (ST_RING - 1);
-    tad[t] = row * 128 + (((row ^ kq) & 7) << 4);
+    const int rr = px + (t / 3) * a.W + (t % 3) - a.W - 1 - Pbase;     // 0 <= rr < 768 in the first step
+    tad[t] = (unsigned)(rr * 128 + ((kh ^ st_sw(rr)) << 4));
   }
 
-  // ---- per-thread state of the store side: pixel slot tid >> 3, channel chunk tid & 7 --------------------------------------------
+  // ---- per-thread state of the store side: pixel slots tid >> 3 and 64 + (tid >> 3), channel chunk tid & 7 -----------------------
   const int spx = tid >> 3, sch = tid & 7, sc = n0 + sch * 8;
   const int stage_rd = ST_STAGE + spx * ST_OLD + sch * 16;
   const bool fwd_acc = !BNEPI && !stat_sum && bn.acc;
@@ -130,26 +159,30 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
   const __amdgpu_buffer_rsrc_t rBy2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(bn.y2), 0, EPI == 2 ? (int)ybytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rMk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(bn.mask), 0, (BNEPI && bn.mask) ? (int)(ybytes >> 4) : 0, 0x00020000);
   const unsigned nomask = (BNEPI && bn.mask) ? 0u : 0xffu;
-  st_v4u e_yv = {0u, 0u, 0u, 0u}, e_ev = e_yv, e_y2 = e_yv;
-  unsigned e_mk = 0xffu, e_off = 0xfffffff0u;                     // byte offset of this thread's 16 bytes of the block (out of range: none)
+  const st_v4u zero4 = {0u, 0u, 0u, 0u};
+  st_v4u e_yv[2] = {zero4, zero4}, e_ev[2] = {zero4, zero4}, e_y2[2] = {zero4, zero4};
+  unsigned e_mk[2] = {0xffu, 0xffu}, e_off[2] = {0xfffffff0u, 0xfffffff0u};     // byte offsets of this thread's 2 x 16 bytes of the block (out of range: none)
   // global reads of the store side for block `it` (requested one step before they are used); out-of-range offsets read zeros
   auto epi_load = [&](int it) {
-    const int m = P0 + 64 * it + spx;
-    e_off = m < P1 ? ((unsigned)m * (unsigned)ldy + (unsigned)sc) * 2u : 0xfffffff0u;
-    if constexpr (BNEPI) {
-      e_yv = __builtin_amdgcn_raw_buffer_load_b128(rBy, (int)e_off, 0, 0);
-      e_mk = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rMk, (int)(e_off >> 4), 0, 0) | nomask;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int m = P0 + ST_STEP * it + 64 * b + spx;
+      e_off[b] = m < P1 ? ((unsigned)m * (unsigned)ldy + (unsigned)sc) * 2u : 0xfffffff0u;
+      if constexpr (BNEPI) {
+        e_yv[b] = __builtin_amdgcn_raw_buffer_load_b128(rBy, (int)e_off[b], 0, 0);
+        e_mk[b] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rMk, (int)(e_off[b] >> 4), 0, 0) | nomask;
+      }
+      if constexpr (EPI == 2) e_y2[b] = __builtin_amdgcn_raw_buffer_load_b128(rBy2, (int)e_off[b], 0, 0);
+      if constexpr (ACC) e_ev[b] = __builtin_amdgcn_raw_buffer_load_b128(rAdd, (int)e_off[b], 0, 0);
     }
-    if constexpr (EPI == 2) e_y2 = __builtin_amdgcn_raw_buffer_load_b128(rBy2, (int)e_off, 0, 0);
-    if constexpr (ACC) e_ev = __builtin_amdgcn_raw_buffer_load_b128(rAdd, (int)e_off, 0, 0);
   };
-  // store side of one block (staged by the previous step): the arithmetic of conv_common.h tile_epilogue, branch-free
-  auto store_block = [&](st_v4u sv) {
+  // store side of one half block (staged by the previous step): the arithmetic of conv_common.h tile_epilogue, branch-free
+  auto store_block = [&](int b, st_v4u sv) {
     uint4 v = make_uint4(sv.x, sv.y, sv.z, sv.w);
     float g8[8], y8[8];
     if constexpr (ACC) {                              // gradient fan-in: float32 add, one rounding
       unpack_bf8(v, g8);
-      unpack_bf8(make_uint4(e_ev.x, e_ev.y, e_ev.z, e_ev.w), y8);
+      unpack_bf8(make_uint4(e_ev[b].x, e_ev[b].y, e_ev[b].z, e_ev[b].w), y8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) g8[j] += y8[j];
       v = pack_bf8(g8);
@@ -158,21 +191,18 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
       unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        w4[q] = (((e_mk >> (2 * q)) & 1u) ? (w4[q] & 0xffffu) : 0u) | (((e_mk >> (2 * q + 1)) & 1u) ? (w4[q] & 0xffff0000u) : 0u);
+        w4[q] = (((e_mk[b] >> (2 * q)) & 1u) ? (w4[q] & 0xffffu) : 0u) | (((e_mk[b] >> (2 * q + 1)) & 1u) ? (w4[q] & 0xffff0000u) : 0u);
       v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
     const st_v4u ov = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(ov, rY, (int)e_off, 0, 0);      // (out-of-range offsets are dropped)
-    const bool live = e_off != 0xfffffff0u;
-    unpack_bf8(v, g8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g8[j] = live ? g8[j] : 0.f;
+    __builtin_amdgcn_raw_buffer_store_b128(ov, rY, (int)e_off[b], 0, 0);      // (out-of-range offsets are dropped)
+    unpack_bf8(v, g8);                                // (pixels beyond the range: every tap was masked, the staged value is 0)
     if constexpr (BNEPI) {
-      unpack_bf8(make_uint4(e_yv.x, e_yv.y, e_yv.z, e_yv.w), y8);
+      unpack_bf8(make_uint4(e_yv[b].x, e_yv[b].y, e_yv[b].z, e_yv[b].w), y8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s0[j] += g8[j]; s1[j] += g8[j] * ((y8[j] - mu[j]) * rs[j]); }
       if constexpr (EPI == 2) {
-        unpack_bf8(make_uint4(e_y2.x, e_y2.y, e_y2.z, e_y2.w), y8);
+        unpack_bf8(make_uint4(e_y2[b].x, e_y2[b].y, e_y2[b].z, e_y2[b].w), y8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s2[j] += g8[j] * ((y8[j] - mu2[j]) * rs2[j]);
       }
@@ -182,71 +212,145 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
     }
   };
 
-  const int npiece0 = ((P0 + a.e0) >> 3) + wave;                  // this wave's piece of step 0
-  // one step: the store side of the previous block, the ring piece of step it + 2, 9 taps x (2 fragment reads, 4 MFMAs)
-  auto step = [&](int it, bool compute) {
-    // the pieces of steps <= it - 2 and the store side's reads of block it - 1 have landed (outstanding: the piece of step it - 1);
-    // every wave has finished step it - 1 (its ring reads, its staged fragment)
-    asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const st_v4u staged = *reinterpret_cast<const st_v4u*>(smem + stage_rd + ((it + 1) & 1) * (64 * ST_OLD));     // block it - 1 (it = 0: unused)
-    if (!compute) { store_block(staged); return; }
-    // tap addresses: masked taps (SAME padding, row wrap, image boundary, pixels beyond M) read the zero row
-    const unsigned cb = (px_ > 0 ? 1u : 0u) | 2u | (px_ < a.W - 1 ? 4u : 0u);
-    unsigned ok = (py_ > 0 ? cb : 0u) | (cb << 3) | (py_ < a.H - 1 ? (cb << 6) : 0u);
-    ok = px < a.M ? ok : 0u;
-    int addr[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int m = __builtin_amdgcn_sbfe((int)ok, t, 1);
-      addr[t] = (tad[t] & m) | (zero_addr & ~m);
-      tad[t] = (tad[t] + 64 * 128) & (ST_RING * 128 - 1);          // the next step's pixel: 64 ring rows on (64 % 8 == 0: same swizzle)
-    }
-    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    {
-      const int j = npiece0 + 8 * it;
-      buffer_load_lds16(a.src, a.src_bytes, smem + ((j * 8) & (ST_RING - 1)) * 128, (unsigned)(j * 1024 + lane_src));
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const bf16x8_t p0 = *reinterpret_cast<const st_lds_frag_t*>(addr[t]);            // (dynamic LDS starts at address 0: no base add)
-      const bf16x8_t p1 = *reinterpret_cast<const st_lds_frag_t*>(addr[t] ^ 64);
-      acc0 = YOLO_MFMA_16x16x32(wreg[0][2 * t], p0, acc0);
-      acc1 = YOLO_MFMA_16x16x32(wreg[1][2 * t], p0, acc1);
-      acc0 = YOLO_MFMA_16x16x32(wreg[0][2 * t + 1], p1, acc0);
-      acc1 = YOLO_MFMA_16x16x32(wreg[1][2 * t + 1], p1, acc1);
-      if (t == 1) { store_block(staged); epi_load(it); }           // (their VALU work goes under the MFMAs of the taps around them)
-    }
-    st_v4u o;
-    o.x = pack_bf2(acc0[0], acc0[1]); o.y = pack_bf2(acc0[2], acc0[3]);
-    o.z = pack_bf2(acc1[0], acc1[1]); o.w = pack_bf2(acc1[2], acc1[3]);
-    *reinterpret_cast<st_v4u*>(smem + stage_wr + (it & 1) * (64 * ST_OLD)) = o;
-    px += 64;
-    px_ += 64;
-    if (px_ >= a.W) { px_ -= a.W; py_ = py_ + 1 == a.H ? 0 : py_ + 1; }     // (W >= 64: one wrap at most)
+  // this wave's two ring pieces per step: pieces K0 + 16 (it + 1) + 2 wave + {0, 1} -- the pixels of step it + 3
+  int pdst = ((K0 + 2 * wave) * 1024) % ST_RING_BYTES;
+  int psrc = (Pbase + 8 * (K0 + 2 * wave)) * 128;
+  const int ls0 = lane_src(K0 & 1), ls1 = lane_src((K0 + 1) & 1);
+  auto issue_piece = [&](int j) {
+    if (j == 0) { buffer_load_lds16(a.src, a.src_bytes, smem + pdst, (unsigned)(psrc + ls0)); return; }
+    const int d1 = pdst + 1024 >= ST_RING_BYTES ? pdst + 1024 - ST_RING_BYTES : pdst + 1024;
+    buffer_load_lds16(a.src, a.src_bytes, smem + d1, (unsigned)(psrc + 1024 + ls1));
+    pdst = pdst + 16 * 1024 >= ST_RING_BYTES ? pdst + 16 * 1024 - ST_RING_BYTES : pdst + 16 * 1024;
+    psrc += 16 * 1024;
   };
-  for (int it = 0; it < niter; ++it) step(it, true);               // (step 0's store side sees e_off out of range: nothing is stored or summed)
-  step(niter, false);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last two pieces are never read; nothing may be in flight into LDS at the end)
+  issue_piece(0);                                                  // the pixels of step 2 (the prologue brought those of steps 0 and 1)
+  issue_piece(1);
+  // tap masks: SAME padding, row wrap, image boundary, pixels beyond M read the zero row
+  auto tap_bits = [&]() {
+    const unsigned cb = (px_ > 0 ? 1u : 0u) | 2u | (px_ < a.W - 1 ? 4u : 0u);
+    const unsigned ok_ = (py_ > 0 ? cb : 0u) | (cb << 3) | (py_ < a.H - 1 ? (cb << 6) : 0u);
+    return px < a.M ? ok_ : 0u;
+  };
+  unsigned ok = tap_bits();
+  // the masked address of tap t for the coming step; the unmasked one moves 128 ring rows per step (128 % 16 == 0: same swizzle)
+  auto tap_addr = [&](int t) {
+    const int m = __builtin_amdgcn_sbfe((int)ok, t, 1);
+    const int ad = ((int)tad[t] & m) | (zero_addr & ~m);
+    const unsigned x = tad[t] + ST_STEP * 128, y = tad[t] + ST_STEP * 128 - ST_RING_BYTES;
+    tad[t] = x < y ? x : y;
+    return ad;
+  };
+  __syncthreads();                                                 // the zero row is written
+  // the first three fragments of a step are requested at the END of the step before it (before the barrier between them: the pieces a
+  // step reads have landed one step earlier), so that the MFMAs resume right behind the barrier
+  bf16x8_t fr[4];
+  int cur = tap_addr(0), nxt = 0;
+  fr[0] = *reinterpret_cast<const st_lds_frag_t*>(cur);            // (dynamic LDS starts at address 0: no base add)
+  fr[1] = *reinterpret_cast<const st_lds_frag_t*>(cur ^ 32);
+  fr[2] = *reinterpret_cast<const st_lds_frag_t*>(cur ^ 64);
+  // one step: the store side of the previous block, the ring pieces of step it + 3, 36 fragment reads and 36 MFMAs (32x32x16)
+  auto step = [&](int it, bool compute, auto phase) {
+    constexpr int PH = decltype(phase)::value;        // the two waves of a SIMD (halves nh = 0 / 1) place the store side under different MFMAs
+    // the pieces of steps <= it + 1 and the store side's reads of block it - 1 have landed (outstanding: the two pieces issued in step
+    // it - 1); every wave has finished step it - 1 (its ring reads, its staged fragment: the 3 youngest LDS operations are the fragment reads)
+    if (it < 32) ST_STAMP(4 + it);
+    if (compute) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(3)" ::: "memory");
+    else         asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    if (it == 5) ST_STAMP(46);
+#ifndef ST_NOBARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+    if (it == 5) ST_STAMP(47);
+    const int sbuf = ((it + 1) & 1) * (ST_STEP * ST_OLD);                                              // block it - 1 (it = 0: zeros)
+    const st_v4u stagedA = *reinterpret_cast<const st_v4u*>(smem + stage_rd + sbuf);
+    const st_v4u stagedB = *reinterpret_cast<const st_v4u*>(smem + stage_rd + sbuf + 64 * ST_OLD);
+    if (!compute) { store_block(0, stagedA); store_block(1, stagedB); return; }
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // software pipeline, fenced so that the compiler keeps it: the fragment of substep s + 3 is requested BEFORE the MFMA of substep s, and the
+    // step's other work (next tap address, ring pieces, store side, its global reads) is spread under the MFMAs
+#pragma unroll
+    for (int s_ = 0; s_ < 36; ++s_) {
+      if (it == 5 && (s_ & 3) == 0) ST_STAMP(48 + (s_ >> 2));
+      if (s_ + 3 < 36) {
+        const int base = ((s_ + 3) >> 2) == (s_ >> 2) ? cur : nxt;
+        fr[(s_ + 3) & 3] = *reinterpret_cast<const st_lds_frag_t*>(base ^ (((s_ + 3) & 3) << 5));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if ((s_ & 3) == 0 && (s_ >> 2) + 1 < 9) nxt = tap_addr((s_ >> 2) + 1);
+#ifndef ST_NOMFMA
+      acc = YOLO_MFMA_32x32x16(wreg[s_], fr[s_ & 3], acc);
+#else
+      acc[s_ & 15] += (float)fr[s_ & 3][0] + (float)wreg[s_][1];
+#endif
+#ifndef ST_NODMA
+      if (s_ == 1 + 8 * PH) issue_piece(0);
+      if (s_ == 2 + 8 * PH) issue_piece(1);
+#endif
+#ifndef ST_NOSTORE
+      if (s_ == 5 + 14 * PH) store_block(0, stagedA);
+      if (s_ == 13 + 14 * PH) store_block(1, stagedB);
+#endif
+      if (s_ == 21 + 12 * PH) epi_load(it);
+      if (s_ == 33) {                                               // (after the step's last tap_addr: the masks of the NEXT step)
+        px += ST_STEP;
+        px_ += ST_STEP;
+        if (px_ >= a.W) { px_ -= a.W; py_ = py_ + 1 == a.H ? 0 : py_ + 1; }     // (W >= 64: two wraps at most)
+        if (px_ >= a.W) { px_ -= a.W; py_ = py_ + 1 == a.H ? 0 : py_ + 1; }
+        ok = tap_bits();
+      }
+      if ((s_ & 3) == 3) cur = nxt;
+      if (s_ == 35) cur = tap_addr(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (it == 5) ST_STAMP(57);
+    // accumulator i of lane (pixel, h) is MFMA row (i & 3) + 8 (i >> 2) + 4 h = channel 16 h + i of this wave's 32 (the row permutation of the
+    // weight image): 16 consecutive channels, two 16-byte writes into the staged tile
+    st_v4u o0, o1;
+    o0.x = pack_bf2(acc[0], acc[1]);   o0.y = pack_bf2(acc[2], acc[3]);   o0.z = pack_bf2(acc[4], acc[5]);   o0.w = pack_bf2(acc[6], acc[7]);
+    o1.x = pack_bf2(acc[8], acc[9]);   o1.y = pack_bf2(acc[10], acc[11]); o1.z = pack_bf2(acc[12], acc[13]); o1.w = pack_bf2(acc[14], acc[15]);
+    char* const sw_ = smem + stage_wr + (it & 1) * (ST_STEP * ST_OLD);
+    *reinterpret_cast<st_v4u*>(sw_) = o0;
+    *reinterpret_cast<st_v4u*>(sw_ + 16) = o1;
+    __builtin_amdgcn_sched_barrier(0);
+    fr[0] = *reinterpret_cast<const st_lds_frag_t*>(cur);            // the next step's first fragments (the last step's are never used)
+    fr[1] = *reinterpret_cast<const st_lds_frag_t*>(cur ^ 32);
+    fr[2] = *reinterpret_cast<const st_lds_frag_t*>(cur ^ 64);
+    if (it == 5) ST_STAMP(58);
+  };
+  ST_STAMP(3);
+  if (nh == 0) {                                                    // (step 0's store side sees e_off out of range and a zero tile)
+    for (int it = 0; it < niter; ++it) step(it, true, std::integral_constant<int, 0>());
+  } else {
+    for (int it = 0; it < niter; ++it) step(it, true, std::integral_constant<int, ST_PHASED>());
+  }
+  step(niter, false, std::integral_constant<int, 0>());
+  ST_STAMP(40);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last pieces are never read; nothing may be in flight into LDS at the end)
 
-  // ---- one statistics / partial row per workgroup: threads -> 8-slot groups, then the 8 groups ------------------------------------
+  // ---- one statistics / partial row per workgroup: [64 pixel slots][64 channels] through the (dead) ring, 8 slots per thread, then 8 groups
   const int nq = BNEPI ? (EPI == 2 ? 3 : 2) : ((!ACC && (stat_sum || fwd_acc)) ? 2 : 0);
   if (nq == 0) return;
-  float* const red = reinterpret_cast<float*>(smem + ST_RED);       // [3][8][64]
+  __syncthreads();                                                 // every wave is out of the loop: the ring is dead
+  ST_STAMP(41);
+  float* const red = reinterpret_cast<float*>(smem);               // [3][64][64], then [3][8][64] behind it
+  float* const red2 = red + 3 * 64 * 64;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {                                      // lanes of a wave that share (lane & 7): 8 pixel slots
-    float v0 = s0[j], v1 = s1[j], v2 = s2[j];
+  for (int j = 0; j < 8; ++j) {
+    red[(0 * 64 + spx) * 64 + sch * 8 + j] = s0[j];
+    red[(1 * 64 + spx) * 64 + sch * 8 + j] = s1[j];
+    if constexpr (EPI == 2) red[(2 * 64 + spx) * 64 + sch * 8 + j] = s2[j];
+  }
+  __syncthreads();
+  {
+    const int cl = tid & 63, part = tid >> 6;
+    for (int q = 0; q < nq; ++q) {
+      float t = 0.f;
 #pragma unroll
-    for (int d = 8; d < 64; d <<= 1) {
-      v0 += __shfl_xor(v0, d);
-      v1 += __shfl_xor(v1, d);
-      if constexpr (EPI == 2) v2 += __shfl_xor(v2, d);
-    }
-    if (lane < 8) {
-      red[(0 * 8 + wave) * 64 + lane * 8 + j] = v0;
-      red[(1 * 8 + wave) * 64 + lane * 8 + j] = v1;
-      if constexpr (EPI == 2) red[(2 * 8 + wave) * 64 + lane * 8 + j] = v2;
+      for (int k = 0; k < 8; ++k) t += red[(q * 64 + part * 8 + k) * 64 + cl];
+      red2[(q * 8 + part) * 64 + cl] = t;
     }
   }
   __syncthreads();
@@ -254,7 +358,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
     const int q = tid >> 6, cl = tid & 63;
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) t += red[(q * 8 + w) * 64 + cl];
+    for (int w = 0; w < 8; ++w) t += red2[(q * 8 + w) * 64 + cl];
     if constexpr (BNEPI) {
       if (bn.partial) bn.partial[((size_t)wg_m * 3 + q) * ldy + n0 + cl] = t;
       else yolo_acc_add(bn.acc, 3, ldy, wg_m % YOLO_ACC_NB, q, n0 + cl, t);
@@ -263,28 +367,35 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
       else yolo_acc_add(bn.acc, 2, Kout, wg_m % YOLO_ACC_NB, q, n0 + cl, t);
     }
   }
+  ST_STAMP(42);
 }
 
 bool st_eligible(const yoloconv::Gather& g, int Kout, bool f32) {
   if (f32 || g.den != 1 || g.C0 != 0 || g.S != 3 || g.RS != 9 || g.smul != 1 || g.pad_h != 1 || g.pad_w != 1 || g.s2) return false;
   if (g.Hs != g.Ho || g.Ws != g.Wo || g.C1 != 64 || Kout % 64 != 0) return false;
-  if (g.Wo < 64 || ((g.Wo + 1 + 7) / 8 * 8) + g.Wo + 1 > 320) return false;           // one column wrap per step; the ring's reach
+  const int r8 = (g.Wo + 1 + 7) / 8 * 8;
+  if (g.Wo < 64 || 512 + r8 + g.Wo + 1 > ST_ROWS) return false;                          // two column wraps per step at most; the ring's reach
+  if ((g.Wo + 9 + 256 + r8) * 128 > ST_WT) return false;                                  // the prologue's pieces stay below the weight image
   if ((size_t)g.M * 128 >= (1ull << 31) || (size_t)Kout * 576 * 2 >= (1ull << 31) || (size_t)g.M * Kout * 2 >= (1ull << 31)) return false;
   return true;
 }
 
 }  // namespace
 
-int g_stream = -1;        // "stream" tuning: -1 auto, 0 never, 1 wherever it fits
+// "stream" tuning: -1 auto = forward launches with >= 512 pixels per workgroup (the kernel owns every register and all LDS of its CU: beside
+// the weight-gradient stream of the backward pass its workgroups wait for whole CUs to drain -- measured 78-156 us per launch in the step
+// against 33 alone), 0 never, 1 wherever it fits (tests), 2 = auto for the data gradient as well
+int g_stream = -1;
 
 // 0 = the streaming kernel does not take this problem, else the pixels per workgroup (statistics / partial rows = ceil(M / that))
 int yolo_stream_plan(const yoloconv::Gather& g, int Kout, bool f32, StreamPlanOut* out) {
   if (g_stream == 0 || !st_eligible(g, Kout, f32)) return 0;
   const int ny = Kout / 64;
   const int nxt = ny >= 256 ? 1 : 256 / ny;
-  int span = ((g.M + nxt - 1) / nxt + 63) / 64 * 64;
-  if (g_stream < 0 && span < 512) return 0;            // auto: at least 8 steps behind one weight load
-  if (span < 64) span = 64;
+  int span = ((g.M + nxt - 1) / nxt + ST_STEP - 1) / ST_STEP * ST_STEP;
+  if (g_stream != 1 && span < 512) return 0;           // auto: at least 4 steps behind one weight load
+  if (g_stream < 0 && g.role != 0) return 0;
+  if (span < ST_STEP) span = ST_STEP;
   if (out) { out->span = span; out->nx = (g.M + span - 1) / span; out->ny = ny; out->lds = ST_LDS; }
   return span;
 }
@@ -299,7 +410,7 @@ int st_launch_e(const yoloconv::Gather& g, const StreamPlanOut& pl, const void* 
   a.wt_bytes = (unsigned)((size_t)Kout * 576 * 2);
   a.H = g.Ho; a.W = g.Wo; a.M = g.M;
   a.span = pl.span; a.ny = pl.ny;
-  a.e0 = 128 + (g.Wo + 1 + 7) / 8 * 8;
+  a.e0 = 256 + (g.Wo + 1 + 7) / 8 * 8;
   a.rhw = g.rhw; a.rw = g.rw;
   static bool attr_set = false;
   if (!attr_set) {
@@ -325,3 +436,10 @@ int yolo_stream_launch(const yoloconv::Gather& g, const void* w, void* y, int ld
   if (e.bn.y) return st_launch_a<1>(g, pl, w, y, ldy, accumulate, e, Kout, st);
   return st_launch_a<0>(g, pl, w, y, ldy, accumulate, e, Kout, st);
 }
+
+#ifdef ST_STAMPS
+extern "C" int yolo_debug_st_stamps(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_st_stamps), &p, sizeof(p));
+}
+#endif
