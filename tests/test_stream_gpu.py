@@ -1,8 +1,8 @@
 """GPU parity tests of the weights-in-registers streaming 3x3 / stride-1 convolution of the 64-channel layers (csrc/conv_stream.hip: one
-512-thread workgroup per compute unit walks a contiguous pixel range through a ring of 512 LDS rows, the 64 x 576 weight tile lives in
+512-thread workgroup per compute unit walks a contiguous pixel range through a ring of 896 LDS rows, the 64 x 576 weight tile lives in
 registers) against a float32 reference of the same op -- forward with BatchNorm statistics, data gradient (plain, accumulating, external
 addend) and the data gradient with the BatchNorm-backward reduce in its epilogue.  The kernel is FORCED through
-yolo_set_tuning('stream', 1) (auto takes only ranges of >= 512 pixels per workgroup); the plan's family is asserted.  Tolerances as in
+yolo_set_tuning('stream', 1) (auto takes only forward launches with ranges of >= 512 pixels per workgroup); the plan's family is asserted.  Tolerances as in
 test_kernels_gpu.py: bf16 operands are exact in the float32 reference, the differences are float32 summation order and the bf16 rounding
 of the stored outputs (2^-8 relative)."""
 import math

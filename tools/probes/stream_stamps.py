@@ -22,14 +22,17 @@ ss, sq = torch.zeros(rows, Cout, device=dev), torch.zeros(rows, Cout, device=dev
 for _ in range(5):
     ops.conv2d_fwd(p, x, w, y, stat_sum=ss, stat_sq=sq)
 torch.cuda.synchronize()
-st = torch.zeros(plan['workgroups'] * 64, dtype=torch.int64, device=dev)
+nwg = plan['workgroups']
+st = torch.zeros(nwg * 64 + nwg * 64, dtype=torch.int64, device=dev)
 lib.yolo_debug_st_stamps.restype = C.c_int
 lib.yolo_debug_st_stamps.argtypes = [C.c_void_p]
 assert lib.yolo_debug_st_stamps(st.data_ptr()) == 0
 ops.conv2d_fwd(p, x, w, y, stat_sum=ss, stat_sq=sq)
 torch.cuda.synchronize()
 lib.yolo_debug_st_stamps(None)
-s = st.cpu().reshape(-1, 64).double()
+allst = st.cpu().double()
+s = allst[:nwg * 64].reshape(-1, 64)
+ws = allst[nwg * 64:].reshape(nwg, 8, 8)
 print(plan)
 full = s[:, 4 + 10] > 0                 # workgroups with >= 11 steps
 s = s[full]
@@ -44,4 +47,10 @@ print('  steps: ' + ' '.join('%.0f' % d(5 + i, 4 + i) for i in range(10)))
 print('  loop total                 %8.0f' % d(40, 3))
 print('  drain                      %8.0f' % d(41, 40))
 print('  statistics row             %8.0f' % d(42, 41))
-print('  step 5: vmcnt wait %.0f, barrier %.0f; taps ' % (d(46, 9), d(47, 46)) + ' '.join('%.0f' % d(48 + i + 1, 48 + i) for i in range(9)) + '; pack + stage %.0f; to next step %.0f' % (d(58, 57), d(10, 58)))
+ws = ws[full]
+arr = ws[:, :, 0] - ws[:, :, 0].min(dim=1, keepdim=True).values          # arrival at step 5's barrier, relative to the first wave
+rel = ws[:, :, 1] - ws[:, :, 0].min(dim=1, keepdim=True).values
+print('  step 5 barrier: arrival of waves 0-7 after the first (median): ' + ' '.join('%.0f' % float(arr[:, w].median()) for w in range(8)))
+print('                  release of waves 0-7 after the first arrival:   ' + ' '.join('%.0f' % float(rel[:, w].median()) for w in range(8)))
+per = ws[:, :, 2] - ws[:, :, 1]
+print('  release(5) -> arrival(6) per wave: ' + ' '.join('%.0f' % float(per[:, w].median()) for w in range(8)))

@@ -66,7 +66,17 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 __device__ __forceinline__ float lo2f(uint32_t w) { return __uint_as_float(w << 16); }          // element in the low / high half of a dword
 __device__ __forceinline__ float hi2f(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 #endif
+#ifdef YOLO_FP16
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+#else
+// one v_cvt_pk_bf16_f32 for the pair (the scalar form above costs two conversions and an SDWA or)
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
+  typedef float yolo_f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 yolo_bf16x2_t __attribute__((ext_vector_type(2)));
+  const yolo_f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, yolo_bf16x2_t));
+}
+#endif
 __device__ __forceinline__ void unpack_bf8(const uint4& v, float* f) {
   f[0] = lo2f(v.x); f[1] = hi2f(v.x);
   f[2] = lo2f(v.y); f[3] = hi2f(v.y);

@@ -4,20 +4,26 @@
 // Replaces keras.layers.Conv2D (reference backbone/basic_backbone.py:20-43 via resnet18.py:29-32) and its TF autodiff data gradient on the
 // 64 -> 64 channel layers of the 104 x 104 maps (416 x 416 input).  With C = 64 the whole K extent is 9 taps x 64 channels = 576: a
 // tile kernel (conv3x3_strip_kernel) runs 9 K steps per tile and spends most of a workgroup's life in its prologue, its epilogue and the
-// barrier of every K step (measured 420-470 TFLOP/s on these layers against 700-830 on the deeper ones).  Here:
+// barrier of every K step (41 us alone for the benchmark layer).  Here:
 //
-// * ONE 512-thread workgroup per CU walks a CONTIGUOUS range of `span` pixels (M / 256 rounded up to 64) in steps of 64 pixels.
-// * The 64 x 576 weight tile is read ONCE per workgroup (LDS-DMA into a swizzled image, then 36 ds_read_b128 per lane) and lives in
-//   registers for the whole range: wave (nh, mi) holds the 32 output channels of half nh for all 18 k-substeps (144 VGPRs) and computes
-//   the 16-pixel fragment mi of every step: 36 MFMAs (16x16x32) against 18 fragment reads, no weight traffic at all in the loop.
-// * The pixels live in a ring of 512 LDS rows (64 KiB) addressed by the global pixel index & 511 (the XOR swizzle chunk ^= row & 7 needs
-//   no base: pieces are 8-row aligned in pixel space): every step each wave appends ONE 8-row piece by LDS-DMA, two steps ahead of its
-//   use, waited on with a counted s_waitcnt vmcnt -- one barrier per step.  SAME padding / row wrap / image boundaries: per-lane 9-bit
-//   tap mask, masked taps read a zero row.
-// * The output fragment goes bf16 through a double-buffered LDS tile; the NEXT step's first instructions (all 512 threads: 64 pixels x 8
-//   chunks) store it in whole 128-byte NHWC rows, accumulate the BatchNorm statistics (forward) or run the fused BatchNorm-backward
-//   reduce (data gradient: ReLU mask, fan-in addend, sums of g and g xhat) -- the same arithmetic as conv_common.h tile_epilogue --
-//   with their global reads requested one step earlier.  One statistics / partial row per workgroup.
+// * ONE 512-thread workgroup per CU walks a CONTIGUOUS range of `span` pixels (M / 256 rounded up to 128) in steps of 128 pixels.
+// * The 64 x 576 weight tile is read ONCE per workgroup (LDS-DMA into a swizzled, row-permuted image, then 36 ds_read_b128 per lane) and
+//   lives in registers for the whole range: wave (nh, mi) holds the 32 output channels of half nh for all 36 k-substeps (144 VGPRs) and
+//   computes the 32-pixel fragment mi of every step with 36 v_mfma_f32_32x32x16 against 36 fragment reads -- no weight traffic in the
+//   loop.  (32x32x16 rather than 16x16x32: an MFMA holds the SIMD's vector issue for 8 cycles of its 32 instead of 8 of its 16, and one
+//   lane address serves twice the flops; the first version of this kernel, on 16x16x32, was bound by vector issue at 2800 cycles per 64
+//   pixels.)
+// * The pixels live in a ring of 896 LDS rows (112 KiB) addressed relative to the range start: every step each wave appends TWO 8-row
+//   pieces by LDS-DMA, three steps ahead of their use, waited on with a counted s_waitcnt vmcnt -- one barrier per step, and the first
+//   fragments of a step are requested before the barrier that opens it.  SAME padding / row wrap / image boundaries: a per-lane 9-bit tap
+//   mask; masked taps read a zero row.  Lane addresses advance by a constant per step (128 rows: the same swizzle phase).
+// * The output fragment goes bf16 through a double-buffered LDS tile; during the NEXT step all 512 threads (128 pixels x 8 chunks, two per
+//   thread) store it in whole 128-byte NHWC rows, accumulate the BatchNorm statistics (forward) or run the fused BatchNorm-backward
+//   reduce (data gradient: ReLU mask, fan-in addend, sums of g and g xhat) -- the same arithmetic as conv_common.h tile_epilogue -- with
+//   their global reads requested one step earlier, all of it spread under the MFMAs.  One statistics / partial row per workgroup.
+// * The kernel owns every register and all LDS of its CU.  Alone that is its strength (31 us against 41); beside the weight-gradient
+//   stream of the backward pass its workgroups wait for whole CUs to drain, so the automatic selection takes it for FORWARD launches only
+//   (yolo_stream_plan; measured +1.1 % on the training step).
 #include "conv_common.h"
 
 namespace {
@@ -33,8 +39,18 @@ __device__ unsigned long long* g_st_stamps = nullptr;
     __builtin_amdgcn_sched_barrier(0);                                                                   \
     if (g_st_stamps && threadIdx.x == 0) g_st_stamps[blockIdx.x * 64 + (i)] = t_;                        \
   } while (0)
+// per-wave stamps (lane 0 of every wave), behind the per-workgroup block
+#define ST_WSTAMP(i)                                                                                     \
+  do {                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    unsigned long long t_;                                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (g_st_stamps && (threadIdx.x & 63) == 0) g_st_stamps[gridDim.x * 64 + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = t_; \
+  } while (0)
 #else
 #define ST_STAMP(i) do {} while (0)
+#define ST_WSTAMP(i) do {} while (0)
 #endif
 
 struct StreamArgs {
@@ -56,15 +72,28 @@ constexpr int ST_LDS = 160 * 1024;
 constexpr int ST_WT = ST_LDS - 9 * 8192;             // weight image (prologue only): over the ring's last rows, the zero row and the staged tiles
 static_assert(ST_STAGE + 2 * ST_STEP * ST_OLD <= ST_LDS, "LDS budget");
 
-#ifndef ST_PHASED
-#define ST_PHASED 1
-#endif
 typedef unsigned st_v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x8_t st_lds_frag_t;
 
 // row swizzle of the [rows][64 bf16] images read by the 32x32x16 operand loads (32 consecutive rows, one 16-byte chunk each): the chunk index
 // is XOR-ed with bits 1-3 of the row -- conflict-free for ds_read_b128's lane groups at every row alignment
 __device__ __forceinline__ int st_sw(int row) { return (row >> 1) & 7; }
+
+// the bitwise select (m & a) | (~m & b) with m = bit `bit` of v as a mask (0 / -1): kept opaque so that the compiler does not turn the pair into
+// v_cmp + v_cndmask through VCC (which costs s_nop wait states beside the MFMAs)
+__device__ __forceinline__ int st_select_bit(unsigned v, int bit, int a, int b) {      // bit `bit` of v ? a : b
+  int d;
+  asm("v_bfe_i32 %0, %1, %2, 1\n\tv_bfi_b32 %0, %0, %3, %4" : "=&v"(d) : "v"(v), "s"(bit), "v"(a), "v"(b));
+  return d;
+}
+template <int N>
+__device__ __forceinline__ void st_wait_vmcnt_upto(int n) {      // s_waitcnt vmcnt(n) for a wave-uniform n <= N (the immediate must be a constant)
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else {
+    if (n >= N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    else st_wait_vmcnt_upto<N - 1>(n);
+  }
+}
 
 // EPI: 0 = plain (forward: statistics of the stored values; plain data gradient), 1 = fused BatchNorm-backward reduce, 2 = the same with a
 // second (shortcut) BatchNorm.  ACC: the output is added to `addend` (or to the output buffer itself).  The hot loop is ONE basic block:
@@ -74,7 +103,7 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
                                                              float* __restrict__ stat_sq, int Kout, BnEpi bn) {
   constexpr bool BNEPI = EPI != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform: scalar registers)
   const int nh = wave >> 2, mi = wave & 3;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = tile % a.ny, wg_m = tile / a.ny;
@@ -92,17 +121,17 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
   auto lane_src = [&](int parity) { return lrow * 128 + (((lane & 7) ^ (4 * parity + (lrow >> 1))) << 4); };
   const int K0 = (P0 + a.e0 - Pbase) >> 3;                        // pieces before the first step (< 96: they do not wrap)
   {
-    const int ls = lane_src(wave & 1);
-    for (int k = wave; k < K0; k += 8)
-      buffer_load_lds16(a.src, a.src_bytes, smem + k * 1024, (unsigned)((Pbase + 8 * k) * 128 + ls));
-    // weight image: row R = 32 h + r of tap t holds channel n0 + 32 h + perm(r) -- MFMA row r of the half-h waves (perm: see the accumulators)
+    // weight image first: row R = 32 h + r of tap t holds channel n0 + 32 h + perm(r) -- MFMA row r of the half-h waves (perm: see the accumulators)
     const int R = wave * 8 + lrow, r = R & 31;
     const int ch = n0 + (R & 32) + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
     const unsigned wrow = (unsigned)((ch * 576 + ((lane & 7) ^ st_sw(R)) * 8) * 2);
 #pragma unroll
     for (int t = 0; t < 9; ++t) buffer_load_lds16(a.wt, a.wt_bytes, smem + ST_WT + t * 8192 + wave * 1024, wrow + t * 128);
+    const int ls = lane_src(wave & 1);
+    for (int k = wave; k < K0; k += 8)
+      buffer_load_lds16(a.src, a.src_bytes, smem + k * 1024, (unsigned)((Pbase + 8 * k) * 128 + ls));
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st_wait_vmcnt_upto<12>((K0 - wave + 7) >> 3);                    // the weight pieces have landed (the ring pieces, issued after them, may still fly)
   __syncthreads();
   ST_STAMP(1);
 
@@ -114,8 +143,8 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
     for (int s_ = 0; s_ < 36; ++s_)
       wreg[s_] = *reinterpret_cast<const bf16x8_t*>(smem + ST_WT + (s_ >> 2) * 8192 + R * 128 + (((2 * (s_ & 3) + kh) ^ st_sw(R)) << 4));
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();                                                // the weight image is dead
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                                // the weight image is dead; the prologue's ring pieces have landed
   // the zero row; and zeros in the staged tiles, so that step 0's store side (nothing staged yet, offsets out of range) adds zeros to the sums
   for (int o = tid * 16; o < 128 + 2 * ST_STEP * ST_OLD; o += 512 * 16) *reinterpret_cast<uint4*>(smem + ST_ZERO + o) = make_uint4(0u, 0u, 0u, 0u);
   ST_STAMP(2);
@@ -226,16 +255,18 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
   issue_piece(0);                                                  // the pixels of step 2 (the prologue brought those of steps 0 and 1)
   issue_piece(1);
   // tap masks: SAME padding, row wrap, image boundary, pixels beyond M read the zero row
-  auto tap_bits = [&]() {
-    const unsigned cb = (px_ > 0 ? 1u : 0u) | 2u | (px_ < a.W - 1 ? 4u : 0u);
-    const unsigned ok_ = (py_ > 0 ? cb : 0u) | (cb << 3) | (py_ < a.H - 1 ? (cb << 6) : 0u);
-    return px < a.M ? ok_ : 0u;
+  auto tap_bits = [&]() {                                          // (sign-bit arithmetic: no VCC round trips)
+    const int c0 = (int)((unsigned)(-px_) >> 31);                  // column > 0
+    const int c2 = (int)((unsigned)(px_ - (a.W - 1)) >> 31);       // column < W - 1
+    const int cb = c0 | 2 | (c2 << 2);
+    const int r0 = (-py_) >> 31, r2 = (py_ - (a.H - 1)) >> 31;     // row > 0, row < H - 1 (as masks)
+    const int ok_ = (cb & r0) | (cb << 3) | ((cb << 6) & r2);
+    return (unsigned)(ok_ & ((px - a.M) >> 31));
   };
   unsigned ok = tap_bits();
   // the masked address of tap t for the coming step; the unmasked one moves 128 ring rows per step (128 % 16 == 0: same swizzle)
   auto tap_addr = [&](int t) {
-    const int m = __builtin_amdgcn_sbfe((int)ok, t, 1);
-    const int ad = ((int)tad[t] & m) | (zero_addr & ~m);
+    const int ad = st_select_bit(ok, t, (int)tad[t], zero_addr);
     const unsigned x = tad[t] + ST_STEP * 128, y = tad[t] + ST_STEP * 128 - ST_RING_BYTES;
     tad[t] = x < y ? x : y;
     return ad;
@@ -256,16 +287,21 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
     if (it < 32) ST_STAMP(4 + it);
     if (compute) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(3)" ::: "memory");
     else         asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    if (it == 5) ST_STAMP(46);
-#ifndef ST_NOBARRIER
+    if (it == 5) ST_WSTAMP(0);
+    if (it == 6) ST_WSTAMP(2);
     __builtin_amdgcn_s_barrier();
-#endif
     asm volatile("" ::: "memory");
-    if (it == 5) ST_STAMP(47);
+    if (it == 5) ST_WSTAMP(1);
+    if (it == 6) ST_WSTAMP(3);
     const int sbuf = ((it + 1) & 1) * (ST_STEP * ST_OLD);                                              // block it - 1 (it = 0: zeros)
-    const st_v4u stagedA = *reinterpret_cast<const st_v4u*>(smem + stage_rd + sbuf);
-    const st_v4u stagedB = *reinterpret_cast<const st_v4u*>(smem + stage_rd + sbuf + 64 * ST_OLD);
-    if (!compute) { store_block(0, stagedA); store_block(1, stagedB); return; }
+    st_v4u stagedA, stagedB;
+    if (!compute) {
+      stagedA = *reinterpret_cast<const st_v4u*>(smem + stage_rd + sbuf);
+      stagedB = *reinterpret_cast<const st_v4u*>(smem + stage_rd + sbuf + 64 * ST_OLD);
+      store_block(0, stagedA);
+      store_block(1, stagedB);
+      return;
+    }
     f32x16_t acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -273,39 +309,38 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
     // step's other work (next tap address, ring pieces, store side, its global reads) is spread under the MFMAs
 #pragma unroll
     for (int s_ = 0; s_ < 36; ++s_) {
-      if (it == 5 && (s_ & 3) == 0) ST_STAMP(48 + (s_ >> 2));
       if (s_ + 3 < 36) {
         const int base = ((s_ + 3) >> 2) == (s_ >> 2) ? cur : nxt;
         fr[(s_ + 3) & 3] = *reinterpret_cast<const st_lds_frag_t*>(base ^ (((s_ + 3) & 3) << 5));
       }
       __builtin_amdgcn_sched_barrier(0);
       if ((s_ & 3) == 0 && (s_ >> 2) + 1 < 9) nxt = tap_addr((s_ >> 2) + 1);
-#ifndef ST_NOMFMA
       acc = YOLO_MFMA_32x32x16(wreg[s_], fr[s_ & 3], acc);
-#else
-      acc[s_ & 15] += (float)fr[s_ & 3][0] + (float)wreg[s_][1];
-#endif
-#ifndef ST_NODMA
       if (s_ == 1 + 8 * PH) issue_piece(0);
       if (s_ == 2 + 8 * PH) issue_piece(1);
-#endif
-#ifndef ST_NOSTORE
+      // (the staged tile is read INSIDE the fenced stages, a few MFMAs before its use: hoisted to the barrier, its unpacking sat before the first MFMA)
+      if (s_ == 2 + 14 * PH) stagedA = *reinterpret_cast<const st_v4u*>(smem + stage_rd + sbuf);
       if (s_ == 5 + 14 * PH) store_block(0, stagedA);
+      if (s_ == 10 + 14 * PH) stagedB = *reinterpret_cast<const st_v4u*>(smem + stage_rd + sbuf + 64 * ST_OLD);
       if (s_ == 13 + 14 * PH) store_block(1, stagedB);
-#endif
       if (s_ == 21 + 12 * PH) epi_load(it);
       if (s_ == 33) {                                               // (after the step's last tap_addr: the masks of the NEXT step)
         px += ST_STEP;
         px_ += ST_STEP;
-        if (px_ >= a.W) { px_ -= a.W; py_ = py_ + 1 == a.H ? 0 : py_ + 1; }     // (W >= 64: two wraps at most)
-        if (px_ >= a.W) { px_ -= a.W; py_ = py_ + 1 == a.H ? 0 : py_ + 1; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                               // (W >= 64: two column wraps at most)
+          const int q = px_ - a.W, w1 = q >> 31;
+          px_ = q + (a.W & w1);
+          py_ += 1 + w1;
+        }
+        { const int q = py_ - a.H, w1 = q >> 31; py_ = q + (a.H & w1); }       // (H >= 2, or H == 1 handled by the second line)
+        { const int q = py_ - a.H, w1 = q >> 31; py_ = q + (a.H & w1); }
         ok = tap_bits();
       }
       if ((s_ & 3) == 3) cur = nxt;
       if (s_ == 35) cur = tap_addr(0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (it == 5) ST_STAMP(57);
     // accumulator i of lane (pixel, h) is MFMA row (i & 3) + 8 (i >> 2) + 4 h = channel 16 h + i of this wave's 32 (the row permutation of the
     // weight image): 16 consecutive channels, two 16-byte writes into the staged tile
     st_v4u o0, o1;
@@ -318,13 +353,12 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
     fr[0] = *reinterpret_cast<const st_lds_frag_t*>(cur);            // the next step's first fragments (the last step's are never used)
     fr[1] = *reinterpret_cast<const st_lds_frag_t*>(cur ^ 32);
     fr[2] = *reinterpret_cast<const st_lds_frag_t*>(cur ^ 64);
-    if (it == 5) ST_STAMP(58);
   };
   ST_STAMP(3);
   if (nh == 0) {                                                    // (step 0's store side sees e_off out of range and a zero tile)
     for (int it = 0; it < niter; ++it) step(it, true, std::integral_constant<int, 0>());
   } else {
-    for (int it = 0; it < niter; ++it) step(it, true, std::integral_constant<int, ST_PHASED>());
+    for (int it = 0; it < niter; ++it) step(it, true, std::integral_constant<int, 1>());
   }
   step(niter, false, std::integral_constant<int, 0>());
   ST_STAMP(40);
