@@ -3,8 +3,8 @@
 // 4.8 GFLOP but 88 MB in + 177 MB out at 416^2 / batch 32 -- a pure HBM stream.  The implicit-GEMM kernel spent 132 us on it (one
 // 128-pixel tile per workgroup: prologue, two K-steps behind barriers, three-sync epilogue, 10816 workgroups); this kernel walks image rows:
 //   * a workgroup owns `rows` consecutive output rows of one image and all 64 output channels; per output row it needs input rows
-//     2ho, 2ho+1, 2ho+2, kept in a 3-slot LDS ring (slot = row % 3): two new rows per iteration, prefetched into registers while the
-//     current row is computed, the zero pad column (x = W) and the zero bottom row (y = H) live in LDS
+//     2ho, 2ho+1, 2ho+2, kept in a 3-slot LDS ring (slot = row % 3): two new rows per iteration, requested into registers one
+//     iteration ahead, the zero pad column (x = W) and the zero bottom row (y = H) live in LDS
 //   * K is laid out as tap * 4 + channel (the packed input pixel is [c0 c1 c2 0 0 0 0 0]: one 8-byte LDS read per tap): taps 0..7 fill one
 //     v_mfma_f32_16x16x32 K-step, tap 8 a quarter of a second one; wave w owns output channels 16w..16w+15 and keeps its weights in 8 VGPRs
 //   * the output row is staged in LDS and written as whole 128-byte NHWC pixels; BatchNorm partial statistics (of the values as stored)
@@ -56,9 +56,12 @@ __global__ __launch_bounds__(ST_THREADS) void stem_conv3x3s2_kernel(StemArgs a) 
 
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   constexpr int MAXPF = 6;                                // prefetch registers: 2 rows * W chunks / 256 threads <= 6 (W <= 768)
-  for (int ho = ho0; ho < ho1; ++ho) {
-    // ---- prefetch the two new input rows 2ho+1, 2ho+2 (row H is the zero pad) ----
-    uint4 pf[MAXPF];
+  // the two new input rows of an iteration are requested ONE ITERATION AHEAD into registers (they fly under the MFMA and store phases of
+  // the row before) and written to the ring at the top of their iteration, when nobody reads the slots they replace any more.
+  // (Requested and awaited at the top of the same iteration, as this kernel did until round 3, every row exposed an HBM round trip:
+  // 71 -> 63 us alone at 416^2 / batch 32.)
+  uint4 pf[MAXPF];
+  auto request_rows = [&](int ho) {                       // input rows 2ho+1, 2ho+2 (row H is the zero pad)
     const int rA = 2 * ho + 1;
 #pragma unroll
     for (int k = 0; k < MAXPF; ++k) {
@@ -66,6 +69,10 @@ __global__ __launch_bounds__(ST_THREADS) void stem_conv3x3s2_kernel(StemArgs a) 
       const int rr = rA + (c >= chunks ? 1 : 0), cc = c >= chunks ? c - chunks : c;
       pf[k] = (c < 2 * chunks && rr < a.H) ? *reinterpret_cast<const uint4*>(xin + ((size_t)rr * W + cc) * 8) : make_uint4(0u, 0u, 0u, 0u);
     }
+  };
+  request_rows(ho0);
+  for (int ho = ho0; ho < ho1; ++ho) {
+    const int rA = 2 * ho + 1;
 #pragma unroll
     for (int k = 0; k < MAXPF; ++k) {
       const int c = tid + k * ST_THREADS;
@@ -75,6 +82,7 @@ __global__ __launch_bounds__(ST_THREADS) void stem_conv3x3s2_kernel(StemArgs a) 
       }
     }
     __syncthreads();                                      // rows 2ho .. 2ho+2 are in the ring
+    if (ho + 1 < ho1) request_rows(ho + 1);
     const char* b0 = ring + ((2 * ho + r0) % 3) * rowb + s0 * 16;
     const char* b1 = ring + ((2 * ho + r1) % 3) * rowb + s1 * 16;
     const char* b8 = ring + ((2 * ho + 2) % 3) * rowb + 2 * 16;
