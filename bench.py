@@ -104,6 +104,8 @@ def kernel_rooflines(model, steps, overlap):
             e1.record()
             cin = 3 if p.Cin == 8 else p.Cin     # algorithmic: the RGB stem is 3 of the 8 padded channels
             fam = 'strip' if (is_strip(p) and k.get('bias') is None) else 'other'
+            if fam == 'strip' and fn is saved_fwd and ops.conv2d_fwd_plan(p)['family'] == 'stream':
+                records.append((e0, e1, 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S, 'stream'))     # (also counted in 'strip' below)
             if k.get('bn') is not None:      # data gradient carrying a BatchNorm unit's masking + backward reduce in its epilogue (another instantiation)
                 fam += '_bn'
             records.append((e0, e1, 2.0 * p.N * p.Ho * p.Wo * p.Cout * cin * p.R * p.S, fam))
@@ -120,6 +122,7 @@ def kernel_rooflines(model, steps, overlap):
         return wrapper
 
     n_params = model.g.ps.n
+    saved_fwd = ops.conv2d_fwd
     patched = {'conv2d_fwd': timed_conv(ops.conv2d_fwd), 'conv2d_dgrad': timed_conv(ops.conv2d_dgrad)}
 
     def timed_wgrad(fn):                  # the slab pass of the weight gradient: 2 N Ho Wo Cout Cin R S FLOP as well (timed on ITS launch stream)
@@ -156,7 +159,7 @@ def kernel_rooflines(model, steps, overlap):
             setattr(ops, n, f)
         model.overlap_wgrad, model.g.on_bucket = saved_overlap, saved_bucket
     out = {}
-    for family in ('strip', 'strip_bn', 'other', 'other_bn', 'wgrad3x3', 'wgrad_other', 'wgrad_sum', 'bn_fwd', 'bn_bwd', 'loss', 'optimizer'):
+    for family in ('strip', 'stream', 'strip_bn', 'other', 'other_bn', 'wgrad3x3', 'wgrad_other', 'wgrad_sum', 'bn_fwd', 'bn_bwd', 'loss', 'optimizer'):
         rs = [r for r in records if r[3] == family]
         t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rs)
         work = sum(r[2] for r in rs)
@@ -396,8 +399,10 @@ def main():
         traffic, traffic_src = strip_hbm_traffic()
         tf = alone['strip']['rate'] / 1e12
         tf_in = instep['strip']['rate'] / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel<.., false> (3x3 stride-1 conv forward + plain data-gradient launches, all tile '
-                                                      'variants; the data gradients that also carry a BatchNorm reduce are the dgrad_bn entry)',
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel<.., false> + conv3x3_stream_kernel<0, false> (every 3x3 stride-1 conv forward + '
+                                                      'plain data-gradient launch, all tile variants; the forward launches of the 64-channel layers run '
+                                                      'the streaming kernel: the `stream` entry; the data gradients that also carry a BatchNorm reduce are '
+                                                      'the dgrad_bn entry)',
                            'achieved': round(tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / PEAK_BF16_TFLOPS, 4),
                            'traffic': traffic, 'traffic_unit': 'bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), ' + traffic_src,
                            'avg_launch_ms': round(alone['strip']['avg_launch_ms'], 5), 'launches_per_step': alone['strip']['launches_per_step'],
@@ -405,6 +410,11 @@ def main():
                                      'two-stream schedule the headline runs, where concurrent weight-gradient kernels share the CUs',
                            'in_step': {'achieved': round(tf_in, 2), 'frac': round(tf_in / PEAK_BF16_TFLOPS, 4),
                                        'avg_launch_ms': round(instep['strip']['avg_launch_ms'], 5)},
+                           'stream': {'kernel': 'conv3x3_stream_kernel<0, false> (weights in registers, pixels through an LDS ring, one workgroup per CU): '
+                                                'the forward launches of the 64-channel 3x3 layers; bound by vector-instruction issue (DESIGN.md section 4)',
+                                      'achieved': round(alone['stream']['rate'] / 1e12, 2), 'frac': round(alone['stream']['rate'] / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                      'in_step_achieved': round(instep['stream']['rate'] / 1e12, 2),
+                                      'avg_launch_ms': round(alone['stream']['avg_launch_ms'], 5), 'launches_per_step': alone['stream']['launches_per_step']},
                            'dgrad_bn': {'kernel': 'conv3x3_strip_kernel<.., true> / igemm_fwd_kernel<.., true>: data gradient + ReLU masking + BatchNorm-'
                                                   'backward partial sums of the unit it completes (reads y and the sign bytes on top of the conv operands)',
                                         'strip_achieved': round(alone['strip_bn']['rate'] / 1e12, 2),
