@@ -245,10 +245,11 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
   int pdst = ((K0 + 2 * wave) * 1024) % ST_RING_BYTES;
   int psrc = (Pbase + 8 * (K0 + 2 * wave)) * 128;
   const int ls0 = lane_src(K0 & 1), ls1 = lane_src((K0 + 1) & 1);
-  auto issue_piece = [&](int j) {
-    if (j == 0) { buffer_load_lds16(a.src, a.src_bytes, smem + pdst, (unsigned)(psrc + ls0)); return; }
+  const int src_end = (P1 + a.W + 1) * 128;                       // first byte no step of this range reads: pieces beyond it are not fetched
+  auto issue_piece = [&](int j) {                                 // (they are still issued, out of range: zeros, the same vmcnt arithmetic)
+    if (j == 0) { buffer_load_lds16(a.src, a.src_bytes, smem + pdst, psrc < src_end ? (unsigned)(psrc + ls0) : 0x80000000u); return; }
     const int d1 = pdst + 1024 >= ST_RING_BYTES ? pdst + 1024 - ST_RING_BYTES : pdst + 1024;
-    buffer_load_lds16(a.src, a.src_bytes, smem + d1, (unsigned)(psrc + 1024 + ls1));
+    buffer_load_lds16(a.src, a.src_bytes, smem + d1, psrc + 1024 < src_end ? (unsigned)(psrc + 1024 + ls1) : 0x80000000u);
     pdst = pdst + 16 * 1024 >= ST_RING_BYTES ? pdst + 16 * 1024 - ST_RING_BYTES : pdst + 16 * 1024;
     psrc += 16 * 1024;
   };
