@@ -147,6 +147,10 @@ def load(dtype=None):
     if not os.path.exists(path):
         raise YoloNativeError('%s not found: build it with `make -C %s` (or __graft_entry__.build()); the MI355X path has no '
                               'fallback' % (path, os.path.join(_HERE, 'csrc')))
+    # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so): it must be in the process BEFORE this library is loaded, or the dynamic
+    # loader binds the kernels to the system copy and every launch fails with "no ROCm-capable device is detected" once torch has initialised
+    # the other one (seen with `python __graft_entry__.py smoke`: build() loaded the library before anything had imported torch)
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
