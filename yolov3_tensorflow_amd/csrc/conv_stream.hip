@@ -23,7 +23,9 @@
 //   their global reads requested one step earlier, all of it spread under the MFMAs.  One statistics / partial row per workgroup.
 // * The kernel owns every register and all LDS of its CU.  Alone that is its strength (31 us against 41); beside the weight-gradient
 //   stream of the backward pass its workgroups wait for whole CUs to drain, so the automatic selection takes it for FORWARD launches only
-//   (yolo_stream_plan; measured +1.1 % on the training step).
+//   (yolo_stream_plan; measured +1.1 % on the training step).  The data-gradient instantiations (EPI 1 / 2, ACC) are correct and tested
+//   (tests/test_stream_gpu.py forces them) but not tuned: with the store side's BatchNorm operands on top of the 144 weight registers they
+//   spill 30-120 VGPRs; a backward-pass form needs <= 128 VGPRs and two workgroups per CU (profiles/HISTORY.md, round 3).
 #include "conv_common.h"
 
 namespace {
