@@ -98,6 +98,22 @@ def test_kernel_plans_are_consistent_without_gpu():
         assert ops.conv2d_stat_rows(p) == (M + 127) // 128   # measured choice for 52 x 52 maps
         p1 = ops.conv_problem(N, H, W, 128, 128, 1, 1, 'same')
         assert ops.conv2d_stat_rows(p1) == (M + 127) // 128  # 1x1: never the strip kernel
+        # the streaming kernel of the 64-channel layers: automatic for FORWARD launches with >= 512 pixels per workgroup, one statistics row
+        # per workgroup; the data gradient (whose rows come from conv2d_dgrad_bn_rows) keeps the strip kernel unless forced
+        p64 = ops.conv_problem(32, 104, 104, 64, 64, 3, 1, 'same')
+        M64 = 32 * 104 * 104
+        plan = ops.conv2d_fwd_plan(p64)
+        assert plan['family'] == 'stream' and plan['tile_pixels'] == 1408 and plan['workgroups'] == 246 and plan['lds_bytes'] == 160 * 1024
+        assert ops.conv2d_stat_rows(p64) == 246 and ops.conv2d_dgrad_bn_rows(p64) == (M64 + 255) // 256
+        assert ops.conv2d_fwd_plan(ops.conv_problem(2, 104, 104, 64, 64, 3, 1, 'same'))['family'] == 'strip'       # 128 pixels per workgroup: no
+        assert ops.conv2d_fwd_plan(ops.conv_problem(16, 152, 152, 64, 64, 3, 1, 'same'))['family'] == 'stream'     # 608 x 608 input
+        assert ops.conv2d_fwd_plan(ops.conv_problem(16, 160, 191, 64, 64, 3, 1, 'same'))['family'] == 'stream'     # the widest map the ring reaches
+        assert ops.conv2d_fwd_plan(ops.conv_problem(16, 160, 192, 64, 64, 3, 1, 'same'))['family'] == 'strip'
+        ops.set_tuning('stream', 1)
+        assert ops.conv2d_dgrad_bn_rows(p64) == 246
+        ops.set_tuning('stream', 0)
+        assert ops.conv2d_fwd_plan(p64)['family'] == 'strip' and ops.conv2d_stat_rows(p64) == (M64 + 255) // 256
+        ops.set_tuning('stream', -1)
     finally:
         ops.set_tuning('strip_bm', -1)
         ops.set_tuning('pstrip', 0)

@@ -51,7 +51,9 @@ CASES = [
     (1, 3, 64, 64),          # the narrowest map the kernel takes: 192 pixels, 3 workgroups of one step
     (2, 104, 104, 64),       # the benchmark layer's map: 21632 pixels, ranges that start in the middle of image rows
     (3, 7, 100, 64),         # W + 1 not a multiple of 8; the last workgroup's range ends inside a step
-    (2, 5, 152, 128),        # the widest map the ring reaches (608 x 608 input), two channel tiles
+    (2, 5, 152, 128),        # 608 x 608 input's map, two channel tiles
+    (3, 4, 160, 64),         # 640 x 640 input's map
+    (2, 6, 191, 64),         # the widest map the ring reaches: 512 + roundup8(W + 1) + W + 1 == 896 rows exactly
     (5, 1, 70, 64),          # one-row images: every tap row but the centre one is padding
     (1, 70, 65, 192),        # three channel tiles
     (9, 9, 81, 64),          # ranges that span several images
