@@ -3,6 +3,9 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from yolov3_tensorflow_amd import engine, ops
+for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):      # e.g. YOLO_TUNE=wgrad_min_steps=4 (planned when the model is built)
+    k, v = kv.split('=')
+    ops.set_tuning(k, int(v))
 dev = torch.device('cuda:0')
 model, loss, opt, grids = bench.build_model(sys.argv[1] if len(sys.argv) > 1 else 'resnet-18', 416, 416, 32, 80, dev)
 images, labels = bench.synthetic_batch(32, 416, 416, 80, 0)
