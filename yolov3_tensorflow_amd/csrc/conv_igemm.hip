@@ -1170,6 +1170,7 @@ extern int g_fused_min_chunks;
 extern int g_ew_nt;                  // eltwise.hip
 extern int64_t g_acc_stream_elems;   // eltwise.hip
 extern int g_pool_scatter;
+extern int g_bwd_fin_small;     // eltwise.hip
 extern int g_reduce_cap;        // eltwise.hip
 extern int g_fused_small_chunks;   // eltwise.hip
 
@@ -1192,6 +1193,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "ps_depth")) { YOLO_CHECK_ARG(value == 1 || value == 3, "ps_depth"); g_ps_depth = value; }
   else if (!strcmp(name, "ew_nt")) { YOLO_CHECK_ARG(value >= 0 && value <= 3, "ew_nt"); g_ew_nt = value; }
   else if (!strcmp(name, "acc_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "acc_stream_kelems"); g_acc_stream_elems = (int64_t)value * 1000; }
+  else if (!strcmp(name, "bwd_fin_small")) { YOLO_CHECK_ARG(value == 0 || value == 1, "bwd_fin_small"); g_bwd_fin_small = value; }
   else if (!strcmp(name, "stream")) { YOLO_CHECK_ARG(value >= -1 && value <= 2, "stream"); g_stream = value; }
   else if (!strcmp(name, "pstrip")) { YOLO_CHECK_ARG(value >= -1 && value <= 4, "pstrip"); g_pstrip = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }

@@ -68,38 +68,47 @@ __global__ __launch_bounds__(EW_THREADS) void bn_stats_kernel(const bf16_t* __re
 // Column reduction used by the finalize kernels: one block = 8 channels x 128 row-lanes (1024 threads); lane (rl, c) sums rows
 // rl, rl+128, ... of K quantities in double, then a shared-memory tree over the 128 row-lanes.  (A 32 x 32 shape with one block
 // per 32 channels left a 64-channel layer's 5408 partial rows to 2 workgroups: 42 us of pure load latency per launch.)
-template <int K>
+// NW = waves of the workgroup: 16 (1024 threads, 128 row-lanes) or 4 (256 threads, 32 row-lanes).  The small form exists for the BACKWARD
+// finalize launches: a 1024-thread workgroup needs 16 free wave slots on ONE CU at once, and beside the weight-gradient stream's slab-sum
+// kernel (256-thread workgroups that refill every slot the moment it frees) it starved until that whole kernel had drained -- one
+// bn_bwd_finalize of the step sat 77 us on the main stream (round 3, step timeline); a 4-wave workgroup takes the first slot that frees.
+template <int K, int NW = 16>
 __device__ __forceinline__ bool column_reduce(const float* const (&src)[K], int P, size_t rstride, int C, double (&tot)[K]) {
-  __shared__ double red[K][16][8];
+  constexpr int RL = NW * 8;                               // row-lanes
+  constexpr int NA = NW == 16 ? 4 : 8;                     // independent partial sums = loads in flight per quantity
+  __shared__ double red[K][NW][8];
   const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   double s[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) s[k] = 0.0;
   if (c < C) {
-    // 4 independent float partial sums per quantity keep 4*K loads in flight (the loop is load-latency bound); each float sum
-    // covers <= P/512 rows before it is widened
-    float f[K][4];
+    // NA independent float partial sums per quantity keep NA*K loads in flight (the loop is load-latency bound); each float sum
+    // covers <= P / (NA * RL) rows before it is widened
+    float f[K][NA];
 #pragma unroll
-    for (int k = 0; k < K; ++k) f[k][0] = f[k][1] = f[k][2] = f[k][3] = 0.f;
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int u = 0; u < NA; ++u) f[k][u] = 0.f;
     int p = rl;
-    for (; p + 384 < P; p += 512) {
+    for (; p + (NA - 1) * RL < P; p += NA * RL) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        f[k][0] += src[k][(size_t)p * rstride + c];
-        f[k][1] += src[k][(size_t)(p + 128) * rstride + c];
-        f[k][2] += src[k][(size_t)(p + 256) * rstride + c];
-        f[k][3] += src[k][(size_t)(p + 384) * rstride + c];
-      }
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int u = 0; u < NA; ++u) f[k][u] += src[k][(size_t)(p + u * RL) * rstride + c];
     }
-    for (; p < P; p += 128) {
+    for (; p < P; p += RL) {
 #pragma unroll
       for (int k = 0; k < K; ++k) f[k][0] += src[k][(size_t)p * rstride + c];
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) s[k] = ((double)f[k][0] + (double)f[k][1]) + ((double)f[k][2] + (double)f[k][3]);
+    for (int k = 0; k < K; ++k) {
+      if constexpr (NA == 4) s[k] = ((double)f[k][0] + (double)f[k][1]) + ((double)f[k][2] + (double)f[k][3]);
+      else s[k] = (((double)f[k][0] + (double)f[k][1]) + ((double)f[k][2] + (double)f[k][3])) +
+                  (((double)f[k][4] + (double)f[k][5]) + ((double)f[k][6] + (double)f[k][7]));
+    }
   }
-  // row-lanes of one wave (lane = 8 * (rl & 7) + cl) meet by shuffles, the 16 waves through one LDS exchange (one barrier instead of the
+  // row-lanes of one wave (lane = 8 * (rl & 7) + cl) meet by shuffles, the waves through one LDS exchange (one barrier instead of the
   // eight of a shared-memory tree: these launches are latency, not work)
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -118,7 +127,7 @@ __device__ __forceinline__ bool column_reduce(const float* const (&src)[K], int 
     for (int k = 0; k < K; ++k) {
       double t = 0.0;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) t += red[k][w][cl];
+      for (int w = 0; w < NW; ++w) t += red[k][w][cl];
       tot[k] = t;
     }
   }
@@ -833,12 +842,13 @@ __global__ __launch_bounds__(EW_THREADS) void bn_pool_bwd_reduce_fast_kernel(con
 
 // backward finalize: dgamma = sum g*xhat, dbeta = sum g (written to the flat gradient buffer), and the two per-channel
 // constants of the apply pass k1 = dbeta / M, k2 = dgamma / M.  which = 1 (main branch) or 2 (shortcut BN, uses quantity 2).
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, size_t rstride, size_t qstride, int C,
-                                                               int which, float count, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ k1, float* __restrict__ k2) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int P, size_t rstride, size_t qstride, int C,
+                                                                  int which, float count, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ k1, float* __restrict__ k2) {
   const float* const src[2] = {partial, partial + (size_t)which * qstride};
   double tot[2];
-  if (!column_reduce<2>(src, P, rstride, C, tot)) return;
+  if (!column_reduce<2, NW>(src, P, rstride, C, tot)) return;
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   if (dgamma) dgamma[c] = (float)tot[1];
   if (dbeta) dbeta[c] = (float)tot[0];
@@ -1441,6 +1451,7 @@ inline int reduce_grid(int M, int C) {
 // the operands the concurrent convolutions re-read.  Measured on the whole step (3 alternating runs each, one box): +0.75..1.0 %.  The same
 // hint on the fused data-gradient epilogue's y / addend reads LOST 0.5 %, on the optimizer's streams it was neutral: not applied there.
 int g_ew_nt = 3;
+int g_bwd_fin_small = 1;        // "bwd_fin_small": 1 = 256-thread workgroups for yolo_bn_bwd_finalize (see column_reduce), 0 = 1024
 int g_pool_scatter = 1;         // "pool_scatter": 1 = scatter form of the stem's pooled backward apply (C <= 64), 0 = gather form
 int g_fused_min_chunks = 3;
 int g_fused_small_chunks = 0;   // "bn_fused_small_grid": workgroups of the small-tensor launch; 0 = small tensors use the three-kernel path
@@ -1683,8 +1694,12 @@ extern "C" int yolo_bn_bwd_finalize(const float* partial, int P, int64_t row_str
                                     float* dgamma, float* dbeta, float* k1, float* k2, void* stream) {
   YOLO_CHECK_ARG(partial && k1 && k2 && P > 0 && C > 0 && (which == 1 || which == 2) && count > 0.f, "bad argument");
   YOLO_CHECK_ARG(q_stride >= C && row_stride >= 3 * q_stride, "bad strides");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,
-                     (size_t)q_stride, C, which, count, dgamma, dbeta, k1, k2);
+  if (g_bwd_fin_small)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,
+                       (size_t)q_stride, C, which, count, dgamma, dbeta, k1, k2);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,
+                       (size_t)q_stride, C, which, count, dgamma, dbeta, k1, k2);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
