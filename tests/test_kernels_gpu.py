@@ -681,6 +681,31 @@ def test_small_map_finalize_plus_apply_in_one_launch(dev, M, C, P, res):
             assert torch.equal(u[5], v[5])
 
 
+@pytest.mark.parametrize('P,C', [(85, 512), (169, 256), (676, 128), (1352, 64), (5408, 64), (1, 64), (129, 72)])
+def test_bwd_finalize_small_workgroups_add_in_the_same_order(dev, P, C):
+    """yolo_bn_bwd_finalize on 256-thread workgroups (default; a 1024-thread workgroup starves beside the slab-sum kernel of the other
+    stream) against the 1024-thread form: the same float partial sums, wave butterflies and wave order -- BIT-identical results (the
+    float16 loss curve has 1e-4 of margin to north_star's 1e-3: a merely different summation order is not free)"""
+    from yolov3_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(P + C)
+    part = (torch.randn(P, 3, C, generator=g) * 3.0).to(dev)
+    res = []
+    try:
+        for small in (0, 1):
+            ops.set_tuning('bwd_fin_small', small)
+            out = [torch.full((C,), float('nan'), device=dev) for _ in range(4)]
+            ops.bn_bwd_finalize(part.view(-1), P, C, 1, 1234.0, *out)
+            torch.cuda.synchronize()
+            res.append(out)
+    finally:
+        ops.set_tuning('bwd_fin_small', 1)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # (float partial sums over up to 11 rows before the widening: 1e-6 of the partials' magnitude)
+    torch.testing.assert_close(res[1][1].double(), part[:, 0].double().sum(0), rtol=1e-5, atol=2e-3)
+    torch.testing.assert_close(res[1][0].double(), part[:, 1].double().sum(0), rtol=1e-5, atol=2e-3)
+
+
 @pytest.mark.parametrize('M,Cc,mode', [(32 * 13 * 13, 512, 'plain'), (32 * 26 * 26, 256, 'res'), (32 * 52 * 52, 128, 'bn2'),
                                        (3001, 64, 'res_acc'), (32 * 104 * 104, 64, 'plain'), (32 * 104 * 104 * 2, 64, 'too_big')])
 @pytest.mark.parametrize('small_grid', [0, 128])

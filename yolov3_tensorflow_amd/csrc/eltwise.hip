@@ -7,6 +7,7 @@
 // layers.add (:124), MaxPooling2D (backbone/resnet18.py:60), UpSampling2D+concatenate gradients
 // (yolov3/yolov3_detector.py:115-116,140-141) and the TF autodiff of all of them.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -68,58 +69,75 @@ __global__ __launch_bounds__(EW_THREADS) void bn_stats_kernel(const bf16_t* __re
 // Column reduction used by the finalize kernels: one block = 8 channels x 128 row-lanes (1024 threads); lane (rl, c) sums rows
 // rl, rl+128, ... of K quantities in double, then a shared-memory tree over the 128 row-lanes.  (A 32 x 32 shape with one block
 // per 32 channels left a 64-channel layer's 5408 partial rows to 2 workgroups: 42 us of pure load latency per launch.)
-// NW = waves of the workgroup: 16 (1024 threads, 128 row-lanes) or 4 (256 threads, 32 row-lanes).  The small form exists for the BACKWARD
-// finalize launches: a 1024-thread workgroup needs 16 free wave slots on ONE CU at once, and beside the weight-gradient stream's slab-sum
-// kernel (256-thread workgroups that refill every slot the moment it frees) it starved until that whole kernel had drained -- one
-// bn_bwd_finalize of the step sat 77 us on the main stream (round 3, step timeline); a 4-wave workgroup takes the first slot that frees.
+// NW = waves of the workgroup: 16 (1024 threads, one row-lane per thread) or 4 (256 threads, each thread plays the row-lanes of FOUR of the
+// 16 waves: rl, rl + 32, rl + 64, rl + 96).  The small form exists for the BACKWARD finalize launches: a 1024-thread workgroup needs 16 free
+// wave slots on ONE CU at once, and beside the weight-gradient stream's slab-sum kernel (256-thread workgroups that refill every slot the
+// moment it frees) it starved until that whole kernel had drained -- one bn_bwd_finalize of the step sat 77 us on the main stream (round 3,
+// step timeline); a 4-wave workgroup takes the first slot that frees.  Both forms add the same numbers in the same order (the per-lane float
+// partial sums, the butterfly over a wave's 8 row-lanes, the 16 wave totals in order): bit-identical results -- the float16 build's loss curve
+// holds north_star's 1e-3 with 1e-4 of margin, and a summation order that is merely DIFFERENT (even a more exact one) moves one step across it.
 template <int K, int NW = 16>
 __device__ __forceinline__ bool column_reduce(const float* const (&src)[K], int P, size_t rstride, int C, double (&tot)[K]) {
-  constexpr int RL = NW * 8;                               // row-lanes
-  constexpr int NA = NW == 16 ? 4 : 8;                     // independent partial sums = loads in flight per quantity
-  __shared__ double red[K][NW][8];
-  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  static_assert(NW == 16 || NW == 4, "1024- or 256-thread workgroups");
+  constexpr int V = 16 / NW;                               // virtual waves per real wave
+  __shared__ double red[K][16][8];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;   // rl: 0 .. 8 NW - 1
   const int c = blockIdx.x * 8 + cl;
-  double s[K];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s[V][K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) s[k] = 0.0;
+  for (int v = 0; v < V; ++v)
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[v][k] = 0.0;
   if (c < C) {
-    // NA independent float partial sums per quantity keep NA*K loads in flight (the loop is load-latency bound); each float sum
-    // covers <= P / (NA * RL) rows before it is widened
-    float f[K][NA];
+    // 4 independent float partial sums per quantity and row-lane keep 4*K*V loads in flight (the loop is load-latency bound); each float
+    // sum covers <= P/512 rows before it is widened
+    float f[V][K][4];
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int v = 0; v < V; ++v)
 #pragma unroll
-      for (int u = 0; u < NA; ++u) f[k][u] = 0.f;
-    int p = rl;
-    for (; p + (NA - 1) * RL < P; p += NA * RL) {
+      for (int k = 0; k < K; ++k) f[v][k][0] = f[v][k][1] = f[v][k][2] = f[v][k][3] = 0.f;
+    int p0 = rl;                                           // row-lane v of this thread starts at p0 + 8 NW v
+    for (; p0 + 8 * NW * (V - 1) + 384 < P; p0 += 512) {   // (all V row-lanes have a full step)
 #pragma unroll
-      for (int k = 0; k < K; ++k)
+      for (int v = 0; v < V; ++v)
 #pragma unroll
-        for (int u = 0; u < NA; ++u) f[k][u] += src[k][(size_t)(p + u * RL) * rstride + c];
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) f[v][k][u] += src[k][(size_t)(p0 + 8 * NW * v + 128 * u) * rstride + c];
     }
-    for (; p < P; p += RL) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) f[k][0] += src[k][(size_t)p * rstride + c];
+    for (int v = 0; v < V; ++v) {
+      int p = p0 + 8 * NW * v;
+      for (; p + 384 < P; p += 512) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) f[v][k][u] += src[k][(size_t)(p + 128 * u) * rstride + c];
+      }
+      for (; p < P; p += 128) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) f[v][k][0] += src[k][(size_t)p * rstride + c];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) s[v][k] = ((double)f[v][k][0] + (double)f[v][k][1]) + ((double)f[v][k][2] + (double)f[v][k][3]);
     }
+  }
+  // row-lanes of one (virtual) wave (lane = 8 * (rl & 7) + cl) meet by shuffles, the 16 waves through one LDS exchange (one barrier instead
+  // of the eight of a shared-memory tree: these launches are latency, not work)
+#pragma unroll
+  for (int v = 0; v < V; ++v)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      if constexpr (NA == 4) s[k] = ((double)f[k][0] + (double)f[k][1]) + ((double)f[k][2] + (double)f[k][3]);
-      else s[k] = (((double)f[k][0] + (double)f[k][1]) + ((double)f[k][2] + (double)f[k][3])) +
-                  (((double)f[k][4] + (double)f[k][5]) + ((double)f[k][6] + (double)f[k][7]));
+      s[v][k] += __shfl_xor(s[v][k], 8, 64);
+      s[v][k] += __shfl_xor(s[v][k], 16, 64);
+      s[v][k] += __shfl_xor(s[v][k], 32, 64);
     }
-  }
-  // row-lanes of one wave (lane = 8 * (rl & 7) + cl) meet by shuffles, the waves through one LDS exchange (one barrier instead of the
-  // eight of a shared-memory tree: these launches are latency, not work)
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    s[k] += __shfl_xor(s[k], 8, 64);
-    s[k] += __shfl_xor(s[k], 16, 64);
-    s[k] += __shfl_xor(s[k], 32, 64);
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane < 8) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) red[k][wave][lane] = s[k];
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int k = 0; k < K; ++k) red[k][wave + NW * v][lane] = s[v][k];
   }
   __syncthreads();
   if (rl == 0) {
@@ -127,7 +145,7 @@ __device__ __forceinline__ bool column_reduce(const float* const (&src)[K], int 
     for (int k = 0; k < K; ++k) {
       double t = 0.0;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) t += red[k][w][cl];
+      for (int w = 0; w < 16; ++w) t += red[k][w][cl];
       tot[k] = t;
     }
   }
