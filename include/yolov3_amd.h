@@ -90,7 +90,7 @@ int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info8);
  * kernel for 3x3 stride-1 convolutions (conv_pstrip.hip; changes yolo_conv2d_stat_rows);
  * "stream": -1 (default) the weights-in-registers streaming kernel (conv_stream.hip) for FORWARD 3x3 stride-1 launches with 64 input channels and
  * >= 512 pixels per workgroup / 0 never / 1 wherever it fits, data gradients included / 2 = the automatic rule for data gradients too (changes
- * yolo_conv2d_stat_rows and yolo_conv2d_dgrad_bn_rows); "bwd_fin_small": 1 (default) / 0 yolo_bn_bwd_finalize on 256- or 1024-thread workgroups;
+ * yolo_conv2d_stat_rows and yolo_conv2d_dgrad_bn_rows); "bwd_fin_small": 0 (default) / 1 yolo_bn_bwd_finalize on 1024- or 256-thread workgroups (bit-identical results);
  * "ew_nt": bit mask, default 3: non-temporal loads of the streamed-once operands of the BatchNorm backward (1) / forward (2) apply kernels;
  * "acc_stream_kelems": tensors from this many thousand elements take the streaming form of the accumulator-fed BatchNorm launches;
  * "strip_ws": 0 auto / 2 / 3 weight-ring stages; "s2_classes": 0 / 1 stride-2 data gradient as four dense parity classes;

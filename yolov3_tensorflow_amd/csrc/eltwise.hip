@@ -97,31 +97,53 @@ __device__ __forceinline__ bool column_reduce(const float* const (&src)[K], int 
     for (int v = 0; v < V; ++v)
 #pragma unroll
       for (int k = 0; k < K; ++k) f[v][k][0] = f[v][k][1] = f[v][k][2] = f[v][k][3] = 0.f;
-    int p0 = rl;                                           // row-lane v of this thread starts at p0 + 8 NW v
-    for (; p0 + 8 * NW * (V - 1) + 384 < P; p0 += 512) {   // (all V row-lanes have a full step)
-#pragma unroll
-      for (int v = 0; v < V; ++v)
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) f[v][k][u] += src[k][(size_t)(p0 + 8 * NW * v + 128 * u) * rstride + c];
-    }
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      int p = p0 + 8 * NW * v;
+    if constexpr (V == 1) {
+      int p = rl;
       for (; p + 384 < P; p += 512) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) f[v][k][u] += src[k][(size_t)(p + 128 * u) * rstride + c];
+          for (int u = 0; u < 4; ++u) f[0][k][u] += src[k][(size_t)(p + 128 * u) * rstride + c];
       }
       for (; p < P; p += 128) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) f[v][k][0] += src[k][(size_t)p * rstride + c];
+        for (int k = 0; k < K; ++k) f[0][k][0] += src[k][(size_t)p * rstride + c];
       }
+    } else {
+      // the same additions, all V row-lanes side by side (4 V K loads in flight per trip; a lane's rows 128 t + its start go to partial
+      // sum t & 3 while the group of four is complete, the rest to sum 0 -- absent rows add +0.0f, which changes no bit)
+      for (int t4 = 0; rl + 128 * t4 < P; t4 += 4) {
+        float val[V][K][4];
+        bool full[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const int pb = rl + 8 * NW * v + 128 * t4;
+          full[v] = pb + 384 < P;
+#pragma unroll
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int pr = pb + 128 * u;
+              val[v][k][u] = pr < P ? src[k][(size_t)pr * rstride + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            f[v][k][0] += val[v][k][0];
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+              f[v][k][u] += full[v] ? val[v][k][u] : 0.f;
+              f[v][k][0] += full[v] ? 0.f : val[v][k][u];
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
 #pragma unroll
       for (int k = 0; k < K; ++k) s[v][k] = ((double)f[v][k][0] + (double)f[v][k][1]) + ((double)f[v][k][2] + (double)f[v][k][3]);
-    }
   }
   // row-lanes of one (virtual) wave (lane = 8 * (rl & 7) + cl) meet by shuffles, the 16 waves through one LDS exchange (one barrier instead
   // of the eight of a shared-memory tree: these launches are latency, not work)
@@ -1469,7 +1491,7 @@ inline int reduce_grid(int M, int C) {
 // the operands the concurrent convolutions re-read.  Measured on the whole step (3 alternating runs each, one box): +0.75..1.0 %.  The same
 // hint on the fused data-gradient epilogue's y / addend reads LOST 0.5 %, on the optimizer's streams it was neutral: not applied there.
 int g_ew_nt = 3;
-int g_bwd_fin_small = 1;        // "bwd_fin_small": 1 = 256-thread workgroups for yolo_bn_bwd_finalize (see column_reduce), 0 = 1024
+int g_bwd_fin_small = 0;        // "bwd_fin_small": 1 = 256-thread workgroups for yolo_bn_bwd_finalize (see column_reduce), 0 = 1024 (default: measured equal)
 int g_pool_scatter = 1;         // "pool_scatter": 1 = scatter form of the stem's pooled backward apply (C <= 64), 0 = gather form
 int g_fused_min_chunks = 3;
 int g_fused_small_chunks = 0;   // "bn_fused_small_grid": workgroups of the small-tensor launch; 0 = small tensors use the three-kernel path
