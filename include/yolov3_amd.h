@@ -77,8 +77,9 @@ typedef struct {
  * stat_rows = yolo_conv2d_stat_rows(p) (reduced later by yolo_bn_finalize). */
 int yolo_conv2d_stat_rows(const yolo_conv_problem* p);
 /* Which kernel yolo_conv2d_fwd would launch for p under the current tuning, without launching (tests, tools): info[0] = family (0 implicit
- * GEMM, 1 LDS-resident strip, 2 big-tile strip = conv_pstrip.hip, 3 RGB stem), info[1] / info[2] = pixel / channel tile, info[3] = pixels a
- * tile owns (big-tile: <= info[1]), info[4] = workgroups, info[5] = dynamic LDS bytes (big-tile), info[6] = weight-ring stages (big-tile),
+ * GEMM, 1 LDS-resident strip, 2 big-tile strip = conv_pstrip.hip, 3 RGB stem, 4 weights-in-registers streaming = conv_stream.hip), info[1] / info[2] = pixel /
+ * channel tile, info[3] = pixels a tile owns (big-tile: <= info[1]; streaming: pixels per workgroup), info[4] = workgroups, info[5] = dynamic LDS bytes
+ * (big-tile, streaming), info[6] = weight-ring stages (big-tile),
  * info[7] = reserved.  The data gradient of p is planned like the forward pass of the problem with Cin and Cout swapped. */
 int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info8);
 /* Test / benchmark hook: override a kernel-selection heuristic.  "strip_bm": -1 auto (default), 0 never use the LDS-resident strip
@@ -86,7 +87,7 @@ int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info8);
  * "stem_direct": 1 (default) / 0 the RGB stem (Cin 8, Cout 64, 3x3 stride 2) on its row-walking kernel or on the implicit GEMM (changes yolo_conv2d_stat_rows);
  * "dw_tiled": 1 (default) / 0 the mixed depthwise forward / data gradient on its tiled kernel or on the row-tile kernel, > 1 = workgroups per
  * 64-channel slab of the tiled kernel's persistent grid (default 512);
- * "pstrip": -1 auto (default) / 0 never / 1 + v force variant v (0: 352 pixels x 64 channels, 1: 176 x 128, 2: 384 x 64, 3: 192 x 128) of the one-tile-per-CU
+ * "pstrip": 0 never (default) / -1 auto / 1 + v force variant v (0: 352 pixels x 64 channels, 1: 176 x 128, 2: 384 x 64, 3: 192 x 128) of the one-tile-per-CU
  * kernel for 3x3 stride-1 convolutions (conv_pstrip.hip; changes yolo_conv2d_stat_rows);
  * "stream": -1 (default) the weights-in-registers streaming kernel (conv_stream.hip) for FORWARD 3x3 stride-1 launches with 64 input channels and
  * >= 512 pixels per workgroup / 0 never / 1 wherever it fits, data gradients included / 2 = the automatic rule for data gradients too (changes
@@ -180,7 +181,8 @@ int yolo_bn_finalize_act_fwd(const float* psum, const float* psq, int P, int64_t
                              float* shift, float* mean, float* rstd, const void* y, const void* res, void* out, uint8_t* relu_mask,
                              int64_t M, int relu, void* stream);
 /* Exact cross-workgroup accumulators: BatchNorm statistics WITHOUT partial rows and without a finalize launch.  A block holds, for Q
- * quantities of C channels, 16 buckets of two int64 limbs each (value * 2^20 = hi + lo * 2^-40) plus a flag word; kernels add their
+ * quantities of C channels, YOLO_ACC_NB = 8 buckets of two int64 limbs each (value * 2^20 = hi + lo * 2^-40) plus two trailing words (the first is the
+ * non-finite / out-of-range flag); kernels add their
  * workgroup sums with 64-bit integer atomics, which are associative: the totals are bit-reproducible whatever the arrival order, unlike
  * float atomics.  yolo_acc_words(Q, C) = size of a block in 8-byte words; the caller zeroes all blocks once per step (yolo_zero_words)
  * before the first kernel that adds to them.  Replaces, like the functions above, the statistics of tf.keras BatchNormalization

@@ -148,6 +148,29 @@ def test_process_pool_decode_yields_the_same_batches(tmp_path):
     assert not [f for f in glob.glob('/dev/shm/psm_*') if os.path.getmtime(f) > t_start], 'shared staging segments must be unlinked'
 
 
+def test_process_pool_falls_back_to_threads_without_shared_memory(tmp_path, monkeypatch):
+    """decode_procs is the trainer's default; on a host whose /dev/shm cannot hold the staging slots the loader must warn and
+    take the thread path (same batches) instead of dying in hipHostRegister or with SIGBUS in a worker"""
+    from PIL import Image
+    from yolov3_tensorflow_amd.dataset.file_util import FileUtil
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    rng = np.random.default_rng(2)
+    lines = []
+    for i in range(4):
+        Image.fromarray(rng.integers(0, 255, (48, 56 + 2 * i, 3), dtype=np.uint8)).save(tmp_path / ('%d.png' % i))
+        lines.append('%d.png 0.5 0.5 0.2 0.2 0' % i)
+    (tmp_path / 'label.txt').write_text('\n'.join(lines) + '\n')
+    args = (str(tmp_path / 'label.txt'), str(tmp_path), (64, 64), 2)
+    ref = list(FileUtil.get_dataset(*args, is_augment=False, is_test=True))
+    monkeypatch.setattr(FileUtil, '_shm_free_bytes', staticmethod(lambda: 1 << 20))
+    with pytest.warns(UserWarning, match='falling back to the decode THREADS'):
+        got = list(FileUtil.get_dataset(*args, is_augment=False, is_test=True, decode_procs=2))
+    assert len(got) == len(ref) == 2
+    for (xa, ya, pa), (xb, yb, pb) in zip(ref, got):
+        assert torch.equal(xa, xb) and np.array_equal(ya, yb) and pa == pb
+
+
 def test_augment_image_entry_point():
     """DatasetUtil.augment_image (reference dataset_util.py:105-115: map _augment over a stream of images): the same draws through the
     oracle's augment give the same pixels; the channel order of the input is kept; non-8-bit inputs are refused"""

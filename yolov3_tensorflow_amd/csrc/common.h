@@ -93,12 +93,14 @@ __device__ __forceinline__ uint4 pack_bf8(const float* f) {
 // A float value is added as TWO int64 limbs (value * 2^20 = hi + lo * 2^-40, lo in [0, 2^40)): integer atomics are associative, so the
 // total does not depend on the order in which workgroups arrive -- bit-reproducible, unlike float atomics -- and carries 60 fractional
 // bits (the float32 partial sums are represented exactly unless they are below 2^-36).  Layout of one accumulator block:
-// [YOLO_ACC_NB = 8 buckets][Q quantities][2 limbs][C channels] int64, then one flag word (non-zero: a non-finite value was added; the
-// consumer then produces NaN, as the float path would).  Buckets (workgroup index mod YOLO_ACC_NB) spread the same-address contention.
+// [YOLO_ACC_NB = 8 buckets][Q quantities][2 limbs][C channels] int64, then two words, the first a flag (non-zero: a non-finite value, or one whose
+// magnitude the fixed-point limbs cannot hold, |v| >= 2^42, was added; the consumer then produces NaN -- the float path would have produced inf / NaN or
+// a sum of no significance).  Buckets (workgroup index mod YOLO_ACC_NB) spread the same-address contention.
 #define YOLO_ACC_NB 8
 __host__ __device__ inline size_t yolo_acc_block_words(int Q, int C) { return (size_t)YOLO_ACC_NB * Q * 2 * C + 2; }
 __device__ __forceinline__ void yolo_acc_add(long long* block, int Q, int C, int bucket, int q, int c, float v) {
-  if (!(fabsf(v) <= 3.0e38f)) {                        // inf / NaN
+  // inf / NaN, or beyond the limbs' range: v * 2^20 must stay far inside int64 (2^63) also after thousands of adds into one bucket
+  if (!(fabsf(v) < 4398046511104.0f)) {                // 2^42
     atomicOr(reinterpret_cast<unsigned long long*>(block + (size_t)YOLO_ACC_NB * Q * 2 * C), 1ull);
     return;
   }

@@ -1253,7 +1253,7 @@ extern "C" int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, con
 
 // yolo_conv2d_fwd (16-bit output, no bias) whose BatchNorm statistics go into an exact accumulator block (common.h yolo_acc_*: Q = 2,
 // C = Cout, yolo_acc_words(2, Cout) int64 words, zeroed by the caller before the launch) instead of one partial row per pixel tile: the
-// consumer sums 16 buckets whatever the tile count, so no finalize launch is needed between this kernel and the BatchNorm apply
+// consumer sums YOLO_ACC_NB buckets whatever the tile count, so no finalize launch is needed between this kernel and the BatchNorm apply
 extern "C" int yolo_conv2d_fwd_acc(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd, void* y, int64_t* stat_acc,
                                    void* stream) {
   int rc = check_problem(p);

@@ -85,6 +85,16 @@ class DeviceImagePipeline(object):
         if int(err) != 0:
             raise RuntimeError('hipHostRegister of the shared staging buffer failed (%s)' % err)
 
+    def reserve(self, nbytes):
+        """allocate every slot's staging / device buffers for ``nbytes`` now (raises where the host cannot provide the memory)"""
+        torch = self.torch
+        for slot in self._slots:
+            if slot.stage is None or slot.stage.numel() < nbytes:
+                with torch.cuda.device(self.device):
+                    self._alloc_stage(slot, int(nbytes))
+                    slot.dev = torch.empty(slot.stage.numel(), dtype=torch.uint8, device=self.device)
+                    slot.alloc_stream = torch.cuda.current_stream(self.device)
+
     @staticmethod
     def geometry(h, w, H, W):
         """tf.image.resize_image_with_pad: ratio = max(w/W, h/H) in float64, resized = floor(dim / ratio), offset = floor((target - dim/ratio) / 2)"""
@@ -324,6 +334,14 @@ class FileUtil(object):
         return batches()
 
     @staticmethod
+    def _shm_free_bytes():
+        try:
+            st = os.statvfs('/dev/shm')
+            return int(st.f_bavail) * int(st.f_frsize)
+        except (OSError, AttributeError):
+            return None
+
+    @staticmethod
     def _get_dataset_procs(file_path, image_dir, image_size, batch_size, is_augment, is_test, seed, device, procs, window, rank, world):
         """get_dataset with the JPEG decode on ``procs`` worker PROCESSES (decode_worker.DecodePool: separate interpreters that import PIL and
         NumPy only and never touch the GPU).  The parent plans every batch -- order, labels, augmentation draws, and from the files' header
@@ -335,11 +353,32 @@ class FileUtil(object):
             world = 1 if is_test else int(os.environ.get('WORLD_SIZE', '1'))
         if rank is None:
             rank = 0 if is_test else int(os.environ.get('RANK', '0'))
-        pipe = DeviceImagePipeline(batch_size, image_size, device=device, slots=window + 3, shared=True)
         pool = decode_worker.DecodePool(procs)
-        names, _ = FileUtil._parse_label_file(file_path)
-        paths_all = sorted(set(os.path.join(image_dir, n) for n in names))
-        sizes = dict(zip(paths_all, pool.probe_sizes(paths_all)))
+        pipe = None
+        try:
+            names, _ = FileUtil._parse_label_file(file_path)
+            paths_all = sorted(set(os.path.join(image_dir, n) for n in names))
+            sizes = dict(zip(paths_all, pool.probe_sizes(paths_all)))
+            # the staging slots are POSIX shared-memory segments (/dev/shm) page-locked with hipHostRegister: reserve ALL of them for the
+            # largest possible batch now, where a host that cannot give them (a 64 MB container /dev/shm: SharedMemory(create=True) succeeds
+            # sparsely and the first write dies with SIGBUS) can still be answered with the thread path
+            slots = window + 3
+            worst = sorted((h * w * 3 + 15) // 16 * 16 for h, w in sizes.values())[-batch_size:]
+            slot_bytes = int((sum(worst) + (batch_size - len(worst)) * (worst[-1] if worst else 0)) * 1.25)
+            free = FileUtil._shm_free_bytes()
+            if free is not None and free < slots * slot_bytes + (8 << 20):
+                raise OSError('/dev/shm has %.0f MB free, the %d staging slots need %.0f MB' % (free / 2**20, slots, slots * slot_bytes / 2**20))
+            pipe = DeviceImagePipeline(batch_size, image_size, device=device, slots=slots, shared=True)
+            pipe.reserve(slot_bytes)
+        except (OSError, RuntimeError, MemoryError) as e:
+            import warnings
+            warnings.warn('decode_procs=%d: shared page-locked staging memory is not available (%s); falling back to the decode THREADS '
+                          '(decode_procs=0)' % (procs, e))
+            pool.close()
+            if pipe is not None:
+                pipe.close()
+            return FileUtil.get_dataset(file_path, image_dir, image_size, batch_size, is_augment=is_augment, is_test=is_test, seed=seed,
+                                        device=device, prefetch=window, rank=rank, world=world, decode_procs=0)
 
         def batches():
             inflight = []

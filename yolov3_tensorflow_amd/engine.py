@@ -198,7 +198,7 @@ class Graph(object):
         # small maps: BatchNorm finalize + apply in one launch when a unit has at most this many partial rows (0 = never; forward and
         # backward; ops.bn_finalize_act_fwd / ops.bn_bwd_finalize_apply)
         # BatchNorm statistics through exact int64 accumulators (ops.conv2d_fwd(stat_acc=...), yolo_acc_*): the producing convolution adds
-        # its tile sums with integer atomics -- associative, so bit-reproducible -- into 16 buckets, and the unit's finalize + apply run as ONE
+        # its tile sums with integer atomics -- associative, so bit-reproducible -- into YOLO_ACC_NB = 8 buckets, and the unit's finalize + apply run as ONE
         # launch whatever the layer size (with partial ROWS that only pays below ~128 rows): the separate finalize launches (~5 us of
         # dependent-launch floor each, forward and backward) disappear for every plain conv -> BatchNorm unit.  YOLO_STAT_ACC=0 for A/B runs.
         # Measured (profiles/HISTORY.md, round 3): the one-workgroup-per-CU merged launch wins below ~6 M elements (the 26 x 26 and 13 x 13 maps at

@@ -91,8 +91,22 @@ class YOLOv3Trainer(object):
         self.log_callback = DetailLossLogger(verbose=2)
         self.tensorboard = MyTensorBoard(log_dir=FLAGS.tensorboard_dir)
 
+    CHECK_EVERY = 50      # steps between two reads of the losses / device-protocol checks inside an epoch
+
+    def _check_protocols_collectively(self):
+        """Model.check_device_protocols on every rank; if any rank failed, all ranks raise together (no rank is left waiting in a collective)"""
+        from yolov3_tensorflow_amd import parallel
+        failure = None
+        try:
+            self.model.check_device_protocols()
+        except (RuntimeError, FloatingPointError) as e:
+            failure = e
+        if parallel.agree_any(failure is not None, self.model.device, self.model.process_group):
+            raise failure if failure is not None else RuntimeError('another rank reported a device-protocol failure')
+
     def train(self, train_set, val_set, train_steps=FLAGS.steps_per_epoch, val_steps=FLAGS.validation_steps):
         """reference :99-115.  ``train_set`` yields (images float32 (N,H,W,3) in [0,1] BGR, labels float32 (N, T*5) padded -1)."""
+        import torch
         from yolov3_tensorflow_amd import parallel
         it = iter(train_set)
         stopper = parallel.EarlyStopping(self.stop_min_delta, self.stop_patience)
@@ -108,21 +122,23 @@ class YOLOv3Trainer(object):
             self.optimizer.lr = lr
             if is_main:
                 self.log_callback.on_epoch_begin(epoch)
-            losses = []
-            for _ in range(train_steps):
+            # device scalars, read every CHECK_EVERY steps: one synchronisation per 50 steps keeps the host ahead of the GPU (a read per step
+            # costs ~25 % of a 4 ms step) while a device-protocol failure or non-finite gradients stop the run within 50 steps, not at the
+            # end of a long epoch.  Every rank runs the same number of steps, so the collective decisions below line up.
+            pending, losses = [], []
+            for step in range(train_steps):
                 images, labels = next(it)
-                losses.append(self.model.train_on_batch(images, labels, sync=False))     # device scalars: one synchronisation per epoch
-            import torch
-            losses = torch.stack(losses).double().cpu().numpy()
-            # keras reports the running mean over the epoch; data parallel: the mean over the ranks' shards, the same number everywhere
-            epoch_loss = parallel.agree_mean(float(np.mean(losses)), self.model.device, self.model.process_group)
-            failure = None
-            try:
-                self.model.check_device_protocols()
-            except (RuntimeError, FloatingPointError) as e:
-                failure = e
-            if parallel.agree_any(failure is not None, self.model.device, self.model.process_group):      # all ranks leave together
-                raise failure if failure is not None else RuntimeError('another rank reported a device-protocol failure')
+                pending.append(self.model.train_on_batch(images, labels, sync=False))
+                if len(pending) >= self.CHECK_EVERY or step == train_steps - 1:
+                    losses.extend(torch.stack(pending).double().cpu().numpy().tolist())
+                    pending = []
+                    self._check_protocols_collectively()
+            # keras reports the running mean over the epoch (nan for an epoch of zero steps, as np.mean([]) gave before); data parallel: the
+            # mean over the ranks' shards, the same number everywhere
+            mean = float(np.mean(losses)) if losses else float('nan')
+            epoch_loss = parallel.agree_mean(mean, self.model.device, self.model.process_group)
+            if not losses:
+                self._check_protocols_collectively()
             history['loss'].append(epoch_loss)
             history['lr'].append(lr)
             # the per-head terms as the callbacks see them at the epoch's end (the last step's values, reference yolov3_loss.py:115-134):
