@@ -77,9 +77,9 @@ typedef struct {
  * stat_rows = yolo_conv2d_stat_rows(p) (reduced later by yolo_bn_finalize). */
 int yolo_conv2d_stat_rows(const yolo_conv_problem* p);
 /* Which kernel yolo_conv2d_fwd would launch for p under the current tuning, without launching (tests, tools): info[0] = family (0 implicit
- * GEMM, 1 LDS-resident strip, 2 big-tile strip = conv_pstrip.hip, 3 RGB stem, 4 weights-in-registers streaming = conv_stream.hip), info[1] / info[2] = pixel /
- * channel tile, info[3] = pixels a tile owns (big-tile: <= info[1]; streaming: pixels per workgroup), info[4] = workgroups, info[5] = dynamic LDS bytes
- * (big-tile, streaming), info[6] = weight-ring stages (big-tile),
+ * GEMM, 1 LDS-resident strip, 2 retired (the big-tile kernel of round 3), 3 RGB stem, 4 weights-in-registers streaming = conv_stream.hip, 5 = 32x32x16 / 64 x 64 wave-tile strip kernel = conv_s32.hip), info[1] / info[2] = pixel /
+ * channel tile, info[3] = pixels a tile owns (streaming: pixels per workgroup), info[4] = workgroups, info[5] = dynamic LDS bytes
+ * (streaming, family 5), info[6] = configuration id (family 5),
  * info[7] = reserved.  The data gradient of p is planned like the forward pass of the problem with Cin and Cout swapped. */
 int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info8);
 /* Test / benchmark hook: override a kernel-selection heuristic.  "strip_bm": -1 auto (default), 0 never use the LDS-resident strip
@@ -87,11 +87,12 @@ int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info8);
  * "stem_direct": 1 (default) / 0 the RGB stem (Cin 8, Cout 64, 3x3 stride 2) on its row-walking kernel or on the implicit GEMM (changes yolo_conv2d_stat_rows);
  * "dw_tiled": 1 (default) / 0 the mixed depthwise forward / data gradient on its tiled kernel or on the row-tile kernel, > 1 = workgroups per
  * 64-channel slab of the tiled kernel's persistent grid (default 512);
- * "pstrip": 0 never (default) / -1 auto / 1 + v force variant v (0: 352 pixels x 64 channels, 1: 176 x 128, 2: 384 x 64, 3: 192 x 128) of the one-tile-per-CU
- * kernel for 3x3 stride-1 convolutions (conv_pstrip.hip; changes yolo_conv2d_stat_rows);
  * "stream": -1 (default) the weights-in-registers streaming kernel (conv_stream.hip) for FORWARD 3x3 stride-1 launches with 64 input channels and
  * >= 512 pixels per workgroup / 0 never / 1 wherever it fits, data gradients included / 2 = the automatic rule for data gradients too (changes
  * yolo_conv2d_stat_rows and yolo_conv2d_dgrad_bn_rows); "bwd_fin_small": 0 (default) / 1 yolo_bn_bwd_finalize on 1024- or 256-thread workgroups (bit-identical results);
+ * "s32": -1 (default) the automatic rule of the 32x32x16 strip kernel (conv_s32.hip: 3x3 stride-1 layers below 80 columns; it yields while "strip_bm" is not -1) / 0 never /
+ * 1 + id force tile configuration id (0: 128 x 128, 1: 256 x 64, 2: 128 x 64 K split 2, 3: 64 x 128 K split 2, 4: 64 x 64 K split 4, 5: 256 x 128 on 8 waves, 6: 128 x 128 on 8 waves
+ * K split 2, 7: 256 x 64 on 8 waves K split 2) where it fits (changes yolo_conv2d_stat_rows and yolo_conv2d_dgrad_bn_rows);
  * "ew_nt": bit mask, default 3: non-temporal loads of the streamed-once operands of the BatchNorm backward (1) / forward (2) apply kernels;
  * "acc_stream_kelems": tensors from this many thousand elements take the streaming form of the accumulator-fed BatchNorm launches;
  * "strip_ws": 0 auto / 2 / 3 weight-ring stages; "s2_classes": 0 / 1 stride-2 data gradient as four dense parity classes;

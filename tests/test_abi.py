@@ -74,28 +74,30 @@ def test_kernel_plans_are_consistent_without_gpu():
     p = ops.conv_problem(N, H, W, 128, 128, 3, 1, 'same')
     M = N * H * W
     try:
-        # the one-tile-per-CU kernel (off by default): "auto" takes layers that fill ONE round of <= 256 tiles, a forced variant any layer it fits
-        ops.set_tuning('pstrip', -1)
-        assert ops.conv2d_fwd_plan(p)['family'] == 'strip'        # 52 x 52: two rounds of 338-pixel tiles -> not taken automatically
-        p26 = ops.conv_problem(N, 26, 26, 256, 256, 3, 1, 'same')
-        plan = ops.conv2d_fwd_plan(p26)
-        assert plan['family'] == 'pstrip' and plan['bm'] == 384 and plan['tile_pixels'] == 338 and plan['workgroups'] == 256
-        assert plan['lds_bytes'] <= 160 * 1024 and ops.conv2d_stat_rows(p26) == N * 26 * 26 // 338
-        ops.set_tuning('pstrip', 1)                         # forced 352 x 64 variant: 512 tiles of 338 pixels (6.5 image rows)
+        # 3x3 / stride-1 layers below 80 columns: the 32x32x16 kernel's automatic rule (conv_s32.hip), one statistics row per pixel tile
         plan = ops.conv2d_fwd_plan(p)
-        assert plan['family'] == 'pstrip' and plan['tile_pixels'] == 338 and plan['workgroups'] == 512 and plan['lds_bytes'] <= 160 * 1024
-        assert ops.conv2d_stat_rows(p) == M // 338
-        ops.set_tuning('pstrip', 2)                         # forced 176 x 128 variant: 169 pixels per tile
-        assert ops.conv2d_fwd_plan(p)['tile_pixels'] == 169 and ops.conv2d_stat_rows(p) == M // 169
-        ops.set_tuning('pstrip', 0)
+        assert plan['family'] == 's32' and (plan['bm'], plan['bn']) == (256, 64) and plan['workgroups'] == (M + 255) // 256 * 2
+        assert plan['lds_bytes'] <= 80 * 1024 and ops.conv2d_stat_rows(p) == (M + 255) // 256         # two workgroups per CU
+        p26 = ops.conv_problem(N, 26, 26, 256, 256, 3, 1, 'same')
+        assert ops.conv2d_fwd_plan(p26)['family'] == 's32' and ops.conv2d_stat_rows(p26) == (N * 26 * 26 + 127) // 128
+        assert ops.conv2d_dgrad_bn_rows(p26) == (N * 26 * 26 + 127) // 128       # (the launches with the BatchNorm reduce stay on the strip kernel there: also 128)
+        p13 = ops.conv_problem(N, 13, 13, 512, 512, 3, 1, 'same')
+        assert ops.conv2d_fwd_plan(p13)['family'] == 's32' and ops.conv2d_stat_rows(p13) == (N * 169 + 63) // 64
+        ops.set_tuning('s32', 1)                            # forced 128 x 128 configuration
+        assert ops.conv2d_fwd_plan(p)['bn'] == 128 and ops.conv2d_stat_rows(p) == (M + 127) // 128
+        ops.set_tuning('s32', 0)
+        assert ops.conv2d_fwd_plan(p)['family'] == 'strip'
+        ops.set_tuning('s32', -1)
         ops.set_tuning('strip_bm', 0)                      # implicit-GEMM kernel: 128-pixel tiles for this shape
         assert ops.conv2d_fwd_plan(p)['family'] == 'igemm'
         assert ops.conv2d_stat_rows(p) == (M + 127) // 128
         for bm in (64, 128, 256):
             ops.set_tuning('strip_bm', bm)
             assert ops.conv2d_stat_rows(p) == (M + bm - 1) // bm
+        ops.set_tuning('s32', 0)
         ops.set_tuning('strip_bm', -1)
-        assert ops.conv2d_stat_rows(p) == (M + 127) // 128   # measured choice for 52 x 52 maps
+        assert ops.conv2d_stat_rows(p) == (M + 127) // 128   # the strip kernel's measured choice for 52 x 52 maps
+        ops.set_tuning('s32', -1)
         p1 = ops.conv_problem(N, H, W, 128, 128, 1, 1, 'same')
         assert ops.conv2d_stat_rows(p1) == (M + 127) // 128  # 1x1: never the strip kernel
         # the streaming kernel of the 64-channel layers: automatic for FORWARD launches with >= 512 pixels per workgroup, one statistics row
@@ -116,7 +118,7 @@ def test_kernel_plans_are_consistent_without_gpu():
         ops.set_tuning('stream', -1)
     finally:
         ops.set_tuning('strip_bm', -1)
-        ops.set_tuning('pstrip', 0)
+        ops.set_tuning('s32', -1)
     ws = ops.conv2d_wgrad_workspace_bytes(p)
     assert ws % (128 * 9 * 128 * 4) == 0 and 2 <= ws // (128 * 9 * 128 * 4) <= 384     # whole slabs, one round of workgroups
     mp = ops.mix_problem(N, 104, 104, 64, [0, 32, 48, 56, 64], [3, 5, 7, 9])

@@ -2,9 +2,14 @@
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-out=gpurun_out/r3j_v2
+out=gpurun_out/r4d
 rm -rf $out && mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python bench.py --steps 12 --warmup 4 --backbone resnet-18-v2 --size 608 --batch 16 --dtype fp16 --focal --no-cpu-baseline --no-roofline > $out/trace.log 2>&1 || exit 1
-python tools/trace_analyze.py "$(ls $out/trace/*kernel_trace.csv $out/trace/*/*kernel_trace.csv 2>/dev/null | head -1)" full > $out/step_timeline.txt 2>&1
-rm -rf $out/trace
-sed -n 1,40p $out/step_timeline.txt
+timeout -k 10 600 python -m pytest tests/test_s32_gpu.py -q -x > $out/test_s32.log 2>&1; echo "pytest rc $?" >> $out/test_s32.log
+tail -4 $out/test_s32.log
+timeout -k 10 400 python tools/probes/s32_sweep.py 0,1,2,4,6 3 > $out/sweep.log 2>&1 || { tail -20 $out/sweep.log; exit 1; }
+cat $out/sweep.log
+for args in "1 32 26 26 256 256" "1 32 52 52 128 128" "1 32 104 104 64 64"; do
+  echo "=== s32_stamps $args" >> $out/stamps.log
+  timeout -k 10 120 python tools/probes/s32_stamps.py $args >> $out/stamps.log 2>&1 || { tail -20 $out/stamps.log; exit 1; }
+done
+cat $out/stamps.log

@@ -1,7 +1,7 @@
 """one 3x3 convolution (forward with BatchNorm statistics, or the plain data gradient with --dgrad) timed alone under several tuning
 settings, interleaved in ONE process (the CDNA guide's rule for A/B numbers): median / min microseconds and TFLOP/s per setting.
 
-usage: python tools/probes/conv_one.py N H W Cin Cout "pstrip=0" "pstrip=1,ps_depth=1" "pstrip=1" [--rounds 7] [--iters 20] [--dgrad]
+usage: python tools/probes/conv_one.py N H W Cin Cout "s32=0" "s32=2" "strip_bm=0" [--rounds 7] [--iters 20] [--dgrad]
 (under rocprofv3 --pmc ... -- python tools/probes/conv_one.py ... --rounds 1 --iters 2 for counters)"""
 import argparse, math, os, statistics, sys
 import torch
@@ -31,8 +31,8 @@ fl = 2.0 * N * H * W * Cout * Cin * 9
 
 
 def apply(setting):
-    for k in ('pstrip', 'strip_bm', 'ps_depth', 'stream'):
-        ops.set_tuning(k, {'pstrip': 0, 'strip_bm': -1, 'ps_depth': 3, 'stream': -1}[k])
+    for k in ('s32', 'strip_bm', 'stream'):
+        ops.set_tuning(k, -1)
     for kv in filter(None, setting.split(',')):
         k, v = kv.split('=')
         ops.set_tuning(k, int(v))

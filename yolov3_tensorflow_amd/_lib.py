@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libyolov3_amd.so')
+# (YOLO_LIB_PATH: a diagnostic build of the same C-ABI, csrc/Makefile target `diag`, for the stamp probes under tools/probes -- still the native
+# library or an exception, never a fallback)
+LIB_PATH = os.environ.get('YOLO_LIB_PATH') or os.path.join(_HERE, 'libyolov3_amd.so')
 LIB_PATH_FP16 = os.path.join(_HERE, 'libyolov3_amd_fp16.so')
 
 MAX_ANCHORS = 8

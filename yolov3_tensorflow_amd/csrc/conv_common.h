@@ -1,12 +1,9 @@
-// Pieces shared by the convolution kernels of conv_igemm.hip and conv_pstrip.hip (included into each translation unit; everything lives
+// Pieces shared by the convolution kernels of conv_igemm.hip, conv_stream.hip and conv_s32.hip (included into each translation unit; everything lives
 // in an anonymous namespace): the gather description, the BatchNorm epilogue arguments, address helpers and the tile epilogue.
 #pragma once
 #include "common.h"
 #include <type_traits>
 #include <string.h>
-#ifndef PS_STAMP
-#define PS_STAMP(i) do {} while (0)      // (diagnostic builds of conv_pstrip.hip define it: s_memtime stamps)
-#endif
 
 namespace yoloconv {
 
@@ -27,6 +24,7 @@ struct Gather {
   // stride-1 correlation over dY with 1 or 2 of the 3 taps per dimension, written to every other row / column of dX; the kernel
   // specialises its copy of this struct per class (s2 == 0: everything below is unused)
   int role;            // 0 = forward launch, 1 = data gradient (kernel selection only: the data gradient runs beside the weight-gradient stream)
+  int bnepi;           // 1 = the launch carries the fused BatchNorm-backward reduce (kernel selection only; must agree between the rows query and the launch)
   int s2;
   int s2_ny;           // classes launched (grid y): 4, or 1 = only the even / even class (1x1 stride-2: the other positions get nothing)
   int N, S_full;       // images; tap columns of the (flipped) weight tensor
@@ -56,19 +54,19 @@ struct Epi { float* ssum; float* ssq; BnEpi bn; };
 
 }  // namespace yoloconv
 
-// ---- big-tile 3x3 / stride-1 kernel (conv_pstrip.hip), dispatched from conv_igemm.hip ----
-struct PsPlanOut { int variant, bm, bn, tstride, ring, wp, npieces, tiles; size_t lds; };
-// 0 = the big-tile kernel does not take this problem, else the pixels per tile (statistics / partial rows = ceil(M / that))
-int yolo_pstrip_plan(const yoloconv::Gather& g, int Kout, bool f32, PsPlanOut* out);
-int yolo_pstrip_launch(const yoloconv::Gather& g, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st);
-extern int g_pstrip, g_ps_depth;      // "pstrip" tuning: -1 auto, 0 never, 1 + v = force variant v
-
 // ---- weights-in-registers streaming kernel of the 64-channel 3x3 / stride-1 layers (conv_stream.hip), dispatched from conv_igemm.hip ----
 struct StreamPlanOut { int span, nx, ny; size_t lds; };
 // 0 = the streaming kernel does not take this problem, else the pixels per workgroup (statistics / partial rows = ceil(M / that))
 int yolo_stream_plan(const yoloconv::Gather& g, int Kout, bool f32, StreamPlanOut* out);
 int yolo_stream_launch(const yoloconv::Gather& g, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st);
 extern int g_stream;                  // "stream" tuning (conv_stream.hip)
+
+// ---- 32x32x16 / 64 x 64 wave-tile 3x3 stride-1 kernel (conv_s32.hip), dispatched from conv_igemm.hip ----
+struct S32PlanOut { int id, bm, bn, tiles; size_t lds; };
+// 0 = the kernel does not take this problem, else the pixels per tile (statistics / partial rows = ceil(M / that))
+int yolo_s32_plan(const yoloconv::Gather& g, int Kout, bool f32, S32PlanOut* out);
+int yolo_s32_launch(const yoloconv::Gather& g, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st);
+extern int g_s32;                     // "s32" tuning (conv_s32.hip)
 
 namespace {
 using yoloconv::Gather; using yoloconv::ClassView; using yoloconv::BnEpi; using yoloconv::Epi;
@@ -221,7 +219,6 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
     };
     if constexpr (BNEPI) e_load(0);
     __syncthreads();                                  // every wave is done with the operand ring
-    PS_STAMP(13);
 #pragma unroll
     for (int b = 0; b < PT; ++b) {
       if (b < b_lo || b >= b_hi) continue;            // (a k-group stages the fragments it holds the final sums of)
@@ -241,9 +238,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
         }
       }
     }
-    PS_STAMP(14);
     __syncthreads();
-    PS_STAMP(15);
     constexpr int CPR = BN / 8;                       // 16-byte chunks per row
     bf16_t* Y = reinterpret_cast<bf16_t*>(Yv);
     if constexpr (BNEPI) {   // data gradient of a BatchNorm unit's output: mask, store g, partial sums of g and g xhat
@@ -330,7 +325,6 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
     }
   }
 
-  PS_STAMP(16);
   if (want_stats) {  // one partial row per workgroup: lanes -> 16-lane groups by shuffle, waves along the pixel axis through LDS
     __syncthreads();                                  // every wave is done with the staged output tile
     float* red = reinterpret_cast<float*>(smem);      // [2][SG * WM][BN]

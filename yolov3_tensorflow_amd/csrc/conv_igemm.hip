@@ -987,7 +987,7 @@ Gather fwd_gather(const yolo_conv_problem* p, const void* src0, const void* src1
   g.smul = p->stride; g.pad_h = p->pad_t; g.pad_w = p->pad_l; g.den = 1;
   g.M = p->N * p->Ho * p->Wo; g.Kg = p->R * p->S * p->Cin;
   g.rhw = 1.0f / (float)(g.Ho * g.Wo); g.rw = 1.0f / (float)g.Wo; g.magicS = 65536 / g.S + 1;
-  g.role = 0;
+  g.role = 0; g.bnepi = 0;
   g.s2 = 0; g.N = p->N; g.S_full = p->S; g.wKg = g.Kg; g.OH = p->Ho; g.OW = p->Wo;
   return g;
 }
@@ -1037,9 +1037,15 @@ int pick_strip(const Gather& g, int Kout, bool f32, int* bnp = nullptr) {
   if (lds > 160 * 1024) return 0;
   return bm;
 }
+// the 32x32x16 kernel takes a problem when forced ("s32" > 0), or by its automatic rule while the strip kernel's tile choice is automatic too
+// ("strip_bm" = 0 / 64 / 128 / 256 asks for the implicit-GEMM / a specific strip kernel: tests and A/B runs)
+int s32_plan(const Gather& g, int Kout, bool f32, S32PlanOut* out) {
+  if (g_s32 <= 0 && g_strip_bm != -1) return 0;
+  return yolo_s32_plan(g, Kout, f32, out);
+}
 int stat_rows_for(const Gather& g, int Kout) {
   if (const int sp = yolo_stream_plan(g, Kout, false, nullptr)) return (g.M + sp - 1) / sp;
-  if (const int pb = yolo_pstrip_plan(g, Kout, false, nullptr)) return (g.M + pb - 1) / pb;
+  if (const int s3 = s32_plan(g, Kout, false, nullptr)) return (g.M + s3 - 1) / s3;
   const int sb = pick_strip(g, Kout, false);
   if (sb) return (g.M + sb - 1) / sb;
   const TileCfg t = pick_tile(g.M, Kout);
@@ -1146,7 +1152,7 @@ int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int l
   int sbn = 0;
   if constexpr (!F32) {
     if (!bias && accumulate != 2 && yolo_stream_plan(g, Kout, false, nullptr)) return yolo_stream_launch(g, w, y, ldy, accumulate, e, Kout, st);
-    if (!bias && yolo_pstrip_plan(g, Kout, false, nullptr)) return yolo_pstrip_launch(g, w, y, ldy, accumulate, e, Kout, st);
+    if (!bias && accumulate != 2 && s32_plan(g, Kout, false, nullptr)) return yolo_s32_launch(g, w, y, ldy, accumulate, e, Kout, st);
   }
   if (const int sb = pick_strip(g, Kout, F32, &sbn)) {
     const bool wide = sbn == 128;
@@ -1190,12 +1196,11 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "wgrad_ring")) { YOLO_CHECK_ARG(value == 2 || value == 3, "wgrad_ring"); g_wgrad_ring = value; }
   else if (!strcmp(name, "wgrad_xcd")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_xcd"); g_wgrad_xcd = value; }
   else if (!strcmp(name, "strip_ws")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 3, "strip_ws"); g_strip_ws = value; }
-  else if (!strcmp(name, "ps_depth")) { YOLO_CHECK_ARG(value == 1 || value == 3, "ps_depth"); g_ps_depth = value; }
   else if (!strcmp(name, "ew_nt")) { YOLO_CHECK_ARG(value >= 0 && value <= 3, "ew_nt"); g_ew_nt = value; }
   else if (!strcmp(name, "acc_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "acc_stream_kelems"); g_acc_stream_elems = (int64_t)value * 1000; }
   else if (!strcmp(name, "bwd_fin_small")) { YOLO_CHECK_ARG(value == 0 || value == 1, "bwd_fin_small"); g_bwd_fin_small = value; }
   else if (!strcmp(name, "stream")) { YOLO_CHECK_ARG(value >= -1 && value <= 2, "stream"); g_stream = value; }
-  else if (!strcmp(name, "pstrip")) { YOLO_CHECK_ARG(value >= -1 && value <= 4, "pstrip"); g_pstrip = value; }
+  else if (!strcmp(name, "s32")) { YOLO_CHECK_ARG(value >= -1 && value <= 16, "s32"); g_s32 = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
   return YOLO_OK;
@@ -1222,9 +1227,9 @@ extern "C" int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info) {
     info[0] = 4; info[1] = 64; info[2] = 64; info[3] = sp.span; info[4] = sp.nx * sp.ny; info[5] = (int32_t)sp.lds;
     return YOLO_OK;
   }
-  PsPlanOut pl;
-  if (yolo_pstrip_plan(g, p->Cout, false, &pl)) {
-    info[0] = 2; info[1] = pl.bm; info[2] = pl.bn; info[3] = pl.tstride; info[4] = pl.tiles; info[5] = (int32_t)pl.lds; info[6] = pl.ring;
+  S32PlanOut s3;
+  if (s32_plan(g, p->Cout, false, &s3)) {
+    info[0] = 5; info[1] = s3.bm; info[2] = s3.bn; info[3] = s3.bm; info[4] = s3.tiles; info[5] = (int32_t)s3.lds; info[6] = s3.id;
     return YOLO_OK;
   }
   int sbn = 0;
@@ -1284,7 +1289,7 @@ int dgrad_gather(const yolo_conv_problem* p, const void* dy, Gather* gp, bool ev
   g.smul = 1; g.pad_h = p->R - 1 - p->pad_t; g.pad_w = p->S - 1 - p->pad_l; g.den = p->stride;
   g.M = p->N * p->H * p->W; g.Kg = p->R * p->S * p->Cout;
   g.rhw = 1.0f / (float)(g.Ho * g.Wo); g.rw = 1.0f / (float)g.Wo; g.magicS = 65536 / g.S + 1;
-  g.role = 1;
+  g.role = 1; g.bnepi = 0;
   g.s2 = 0; g.s2_ny = 4; g.N = p->N; g.S_full = p->S; g.wKg = g.Kg; g.OH = p->H; g.OW = p->W;
   YOLO_CHECK_ARG(g.M < (1 << 24), "row decode needs N*H*W < 2^24");
   const bool k3 = p->R == 3 && p->S == 3;
@@ -1369,6 +1374,7 @@ extern "C" int yolo_conv2d_dgrad_bn_rows(const yolo_conv_problem* p) {
   static const char dummy = 0;
   if (!p || dgrad_gather(p, &dummy, &g)) return YOLO_ERR_INVALID_ARG;
   if ((size_t)p->N * p->H * p->W * p->Cin >= (1ull << 31)) return YOLO_ERR_INVALID_ARG;     // 32-bit element offsets in the epilogue
+  g.bnepi = 1;
   return (g.s2 ? 4 : 1) * stat_rows_for(g, p->Cin);
 }
 
@@ -1393,6 +1399,7 @@ extern "C" int yolo_conv2d_dgrad_bn_acc(const yolo_conv_problem* p, const void* 
   Gather g;
   int rc = dgrad_gather(p, dy, &g);
   if (rc) return rc;
+  g.bnepi = 1;
   Epi e = {};
   e.bn.mask = (const uint8_t*)relu_mask;
   e.bn.y = (const bf16_t*)y; e.bn.mean = mean; e.bn.rstd = rstd;

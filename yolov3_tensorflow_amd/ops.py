@@ -62,7 +62,7 @@ def conv2d_stat_rows(p):
     return r
 
 
-CONV_FAMILIES = ('igemm', 'strip', 'pstrip', 'stem', 'stream')
+CONV_FAMILIES = ('igemm', 'strip', 'retired', 'stem', 'stream', 's32')      # (2: the big-tile kernel of round 3, removed in round 4)
 
 
 def conv2d_fwd_plan(p):
