@@ -486,20 +486,18 @@ int yolo_s32_plan(const yoloconv::Gather& g, int Kout, bool f32, S32PlanOut* out
   int id = -1;
   if (g_s32 > 0) id = g_s32 - 1;
   else {
-    // automatic, from tools/probes/s32_sweep.py on the ResNet18-YOLOv3 layers at batch 32 (profiles/r04_s32_sweep.txt; us, this kernel / strip kernel):
-    //  * maps of 80 columns and more (104 x 104 x 64: 9 taps in all) stay on the streaming / strip kernels: ~8 k cycles of setup + epilogue
-    //    per tile against 9 taps of ~1 k (48 / 30 forward, 42 / 35 data gradient);
-    //  * 40-79 columns: 256 x 64 tiles (30 / 35 on 52 x 52 x 128 -> 128, 52 / 60 on 128 -> 256, data gradients alike);
-    //  * 20-39 columns: 256 x 64 forward onto >= 512 channels (48 / 55), else 128 x 64 with the K split (28 / 30, 48 / 51); launches that carry
-    //    the BatchNorm-backward reduce stay on the strip kernel there (its extra registers cost this kernel a workgroup per CU: 35 / 32);
-    //  * below 20 columns: 64 x 64 with K split 4 onto >= 512 channels (32.5 / 34.5), else 128 x 64 with K split 2 (20 / 27 forward)
-    const long px = g.M;
-    if (g.Wo >= 80 || px < 2048) return 0;
+    // automatic: where the kernel shortens the training STEP (kernel trace of the headline step with "s32" = -1 / 0, profiles/r04_s32_ab_*;
+    // us in the step, this kernel / strip kernel).  Timed alone in a loop (tools/probes/s32_sweep.py) it also wins 5-30 % on the 26 x 26 and
+    // 13 x 13 layers, but in the step those launches take the same time on either kernel (27.6 / 27.6, 33.4 / 33.0, 30.6 / 29.1), and in the backward
+    // pass, beside the weight-gradient stream, neither kernel runs at its stand-alone speed -- so the rule is the measured one, not the sweep's:
+    //  * 40-79 columns (52 x 52 x 128 -> 128: 28.2 / 32.9; 128 -> 256: 50.1 / 55.6): 256 x 64 tiles, forward and data gradient;
+    //  * 20-39 columns: forward launches onto >= 512 channels only (26 x 26 x 256 -> 512: 46.2 / 49.9), 256 x 64 tiles;
+    //  * everything else stays on the strip / streaming kernels (80 columns and more: 9 taps in all against ~8 k cycles of setup + epilogue
+    //    per tile, 48 / 30 us alone on 104 x 104 x 64).
+    if (g.M < 2048 || g.Wo >= 80 || g.Wo < 20) return 0;
     if (g.Wo >= 40) id = 1;
-    else if (g.Wo >= 20) {
-      if (g.bnepi) return 0;
-      id = (g.role == 0 && Kout >= 512) ? 1 : 2;
-    } else id = Kout >= 512 ? 4 : 2;
+    else if (g.role == 0 && !g.bnepi && Kout >= 512) id = 1;
+    else return 0;
   }
   if (id < 0 || id >= kNCfg) return 0;
   const S32Cfg& c = kCfg[id];
