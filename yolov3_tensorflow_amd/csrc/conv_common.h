@@ -68,6 +68,12 @@ int yolo_s32_plan(const yoloconv::Gather& g, int Kout, bool f32, S32PlanOut* out
 int yolo_s32_launch(const yoloconv::Gather& g, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st);
 extern int g_s32;                     // "s32" tuning (conv_s32.hip)
 
+// ---- stationary-output weight gradient of the 3x3 stride-1 layers (conv_wgrad9.hip), dispatched from conv_igemm.hip ----
+// 0 = the kernel does not take this problem, else the number of pixel splits (= slabs)
+int yolo_wgrad9_plan(const yolo_conv_problem* p, int* sps_out);
+int yolo_wgrad9_launch(const yolo_conv_problem* p, const void* x, const void* dy, float* out, long long slab, hipStream_t stream);
+extern int g_wgrad9, g_wgrad9_wgs;    // "wgrad9" / "wgrad9_wgs" tuning (conv_wgrad9.hip)
+
 namespace {
 using yoloconv::Gather; using yoloconv::ClassView; using yoloconv::BnEpi; using yoloconv::Epi;
 

@@ -544,6 +544,20 @@ __global__ __launch_bounds__(NW * 64) void igemm_wgrad_kernel(Gather g, const bf
 //    a zero row instead (per-lane address select).
 // X image swizzle: 32-byte group index ^= f(row), f(row) = bit1(row) | bit3(row) << 1 -- conflict-free for ds_read_b64_tr_b16 at every
 // row shift (brute-forced over all alignments).
+// Diagnostic builds only (csrc/Makefile target `diag`, -DWG_STAMPS; tools/probes/wgrad_stamps.py): per wave, s_memtime cycles of the pipelined
+// strip weight gradient summed over its stages in {counted wait, barrier, stage body} and the spans outside the loop.
+#ifdef WG_STAMPS
+__device__ unsigned long long* g_wg_stamps = nullptr;
+#define WG_T(var)                                                                          \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  } while (0)
+#else
+#define WG_T(var) do {} while (0)
+#endif
+
 struct WgradStripArgs {
   const bf16_t* x; unsigned x_bytes;
   const bf16_t* dy; unsigned y_bytes;
@@ -565,6 +579,10 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_strip_kernel(WgradStripArgs a
   constexpr int XIMG = XROWS * 128, YIMG = WG_BP * 256, STAGE = XIMG + YIMG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef WG_STAMPS
+  unsigned long long W0 = 0, W1 = 0, W2 = 0, W3 = 0, wa = 0, wb = 0, wc_ = 0, wd = 0, sw_wait = 0, sw_bar = 0, sw_body = 0;
+#endif
+  WG_T(W0);
   const int wr = wave >> 2, wc = wave & 3;    // wave tile: co [wr*BCO/2, +BCO/2) x ci [wc*16, +16) x 3 taps
   const Bid3 bid = wgrad_block(a.gx, a.gy, a.xcd);
   const int tr = bid.x % 3, cc = bid.x / 3;
@@ -768,9 +786,12 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_strip_kernel(WgradStripArgs a
     };
     auto body = [&](auto bufc) {
       constexpr int B = decltype(bufc)::value;
+      WG_T(wa);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this stage landed; this wave's reads of the other buffer completed
+      WG_T(wb);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      WG_T(wc_);
       const char* base = smem + B * STAGE;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -787,13 +808,19 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_strip_kernel(WgradStripArgs a
 #pragma unroll
           for (int s = 0; s < 3; ++s) acc[c][s] = YOLO_MFMA_16x16x32(yf[c], xf[s], acc[c][s]);
       }
+#ifdef WG_STAMPS
+      WG_T(wd);
+      sw_wait += wb - wa; sw_bar += wc_ - wb; sw_body += wd - wc_;
+#endif
     };
     issue_next(std::integral_constant<int, 0>{});
     select_x(std::integral_constant<int, 0>{});
+    WG_T(W1);
     for (int st = s_begin; st < s_end; st += 2) {
       body(std::integral_constant<int, 0>{});
       if (st + 1 < s_end) body(std::integral_constant<int, 1>{});
     }
+    WG_T(W2);
   } else if (NST == 2) {
     issue_stage(0);
     for (int st = s_begin; st < s_end; ++st) {
@@ -834,6 +861,16 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_strip_kernel(WgradStripArgs a
         else        atomicAdd(dst + (size_t)co * a.Kg + kc, acc[c][s][j]);
       }
     }
+#ifdef WG_STAMPS
+  if constexpr (PIPE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_T(W3);
+    if (g_wg_stamps && lane == 0) {
+      unsigned long long* o = g_wg_stamps + ((size_t)blockIdx.x * 8 + wave) * 16;
+      o[0] = W0; o[1] = W1 - W0; o[2] = W2 - W1; o[3] = W3 - W2; o[4] = sw_wait; o[5] = sw_bar; o[6] = sw_body; o[7] = (unsigned long long)(s_end - s_begin); o[9] = W3;
+    }
+  }
+#endif
 }
 
 // dW[i] (+)= sum over the split slabs: 256 threads = 64 float4 columns x 4 slab groups (coalesced 1 KiB rows, 4-deep unrolled loads),
@@ -1200,6 +1237,8 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "acc_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "acc_stream_kelems"); g_acc_stream_elems = (int64_t)value * 1000; }
   else if (!strcmp(name, "bwd_fin_small")) { YOLO_CHECK_ARG(value == 0 || value == 1, "bwd_fin_small"); g_bwd_fin_small = value; }
   else if (!strcmp(name, "stream")) { YOLO_CHECK_ARG(value >= -1 && value <= 2, "stream"); g_stream = value; }
+  else if (!strcmp(name, "wgrad9_wgs")) { YOLO_CHECK_ARG(value >= 16 && value <= 1024, "wgrad9_wgs"); g_wgrad9_wgs = value; }
+  else if (!strcmp(name, "wgrad9")) { YOLO_CHECK_ARG(value >= -1 && value <= 1, "wgrad9"); g_wgrad9 = value; }
   else if (!strcmp(name, "s32")) { YOLO_CHECK_ARG(value >= -1 && value <= 16, "s32"); g_s32 = value; }
   else if (!strcmp(name, "strip_bn")) { YOLO_CHECK_ARG(value == 0 || value == 64 || value == 128, "strip_bn"); g_strip_bn = value; }
   else YOLO_CHECK_ARG(false, "unknown tuning name");
@@ -1412,7 +1451,7 @@ extern "C" int yolo_conv2d_dgrad_bn_acc(const yolo_conv_problem* p, const void* 
 }
 
 namespace {
-struct WgradPlan { Gather g; int bco, tiles_k, tiles_c, split_k, sps; bool strip; };
+struct WgradPlan { Gather g; int bco, tiles_k, tiles_c, split_k, sps; bool strip, w9; };
 
 // split-K plan: at most `target` workgroups (2 per CU: 64 KiB of LDS each) so that the whole grid is resident in one round -- one
 // workgroup more than the slots costs a second, almost empty round -- and at least 8 pixel-steps per workgroup
@@ -1426,6 +1465,14 @@ int plan_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, i
   pl->strip = g_wgrad_strip && p->R == 3 && p->S == 3 && p->stride == 1 && p->pad_t == 1 && p->pad_l == 1 && p->Ho == p->H &&
               p->Wo == p->W && p->C0 == 0 && p->Cin % 64 == 0 && (size_t)p->N * p->H * p->W * p->Cin * 2 < (1ull << 31) &&
               (size_t)pl->g.M * p->Cout * 2 < (1ull << 31);
+  pl->w9 = false;
+  if (split_k <= 0 && pl->strip) {                    // the stationary-output kernel plans its own pixel splits (one workgroup per CU)
+    int sps9 = 0;
+    if (const int ns = yolo_wgrad9_plan(p, &sps9)) {
+      pl->w9 = true; pl->split_k = ns; pl->sps = sps9; pl->tiles_k = pl->tiles_c = 1;
+      return YOLO_OK;
+    }
+  }
   pl->tiles_k = pl->strip ? 3 * (p->Cin / 64) : (pl->g.Kg + WG_BKC - 1) / WG_BKC;
   pl->tiles_c = (p->Cout + pl->bco - 1) / pl->bco;
   const int nsteps = (pl->g.M + WG_BP - 1) / WG_BP;
@@ -1445,6 +1492,7 @@ int plan_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, i
 // slab = 0: float atomics into out; slab > 0: split z stores its partial tile to out + z * slab
 void launch_wgrad(const yolo_conv_problem* p, const WgradPlan& pl, const void* dy, float* out, long long slab, hipStream_t stream) {
   const Gather& g = pl.g;
+  if (pl.w9) { (void)yolo_wgrad9_launch(p, g.src1, dy, out, slab, stream); return; }
   if (pl.strip) {
     WgradStripArgs a;
     a.x = g.src1; a.x_bytes = (unsigned)((size_t)p->N * p->H * p->W * p->Cin * 2);
@@ -1501,6 +1549,13 @@ void launch_wgrad(const yolo_conv_problem* p, const WgradPlan& pl, const void* d
 }
 
 }  // namespace
+
+#ifdef WG_STAMPS
+extern "C" int yolo_debug_wg_stamps(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_stamps), &p, sizeof(p));
+}
+#endif
 
 extern "C" int yolo_conv2d_wgrad(const yolo_conv_problem* p, const void* src0, const void* src1, const void* dy, float* dw,
                                  int split_k, void* stream) {
