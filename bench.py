@@ -204,7 +204,80 @@ def parity_statement(dtype):
         except (KeyError, ValueError, OSError):
             continue
     out['holds_1e-3_on_every_step'] = [k for k in ('bf16', 'fp16') if k in out and out[k]['within_1e-3'].split('/')[0] == out[k]['within_1e-3'].split('/')[1]]
+    # how much of that is summation order: the same 20 steps under several kernel selections that only reorder float32 partial sums
+    sc = sorted(glob.glob(os.path.join(here, 'r*_loss_curve_scatter.json')))
+    if sc:
+        try:
+            runs = json.load(open(sc[-1]))['runs']
+            out['summation_order_scatter'] = {'source': 'profiles/' + os.path.basename(sc[-1]), 'what': 'tools/loss_curve_scatter.py: the curve under '
+                                              'kernel selections that differ only in the order of float32 partial sums (all pass the kernel parity tests)'}
+            for key, name in (('bf16', 'bfloat16'), ('fp16', 'float16')):
+                rs = [r for r in runs if r['dtype'] == name]
+                if rs:
+                    out['summation_order_scatter'][key] = {'orders': len(rs), 'max_range': [round(min(r['max'] for r in rs), 6), round(max(r['max'] for r in rs), 6)],
+                                                           'median_range': [round(min(r['median'] for r in rs), 6), round(max(r['median'] for r in rs), 6)],
+                                                           'within_1e-3_range': '%d-%d/20' % (min(r['steps_within_1e-3'] for r in rs), max(r['steps_within_1e-3'] for r in rs))}
+        except (KeyError, ValueError, OSError):
+            pass
     return out
+
+
+def fp16_throughput(args, device, steps=20, warmup=5):
+    """the float16 build (libyolov3_amd_fp16.so: the build whose loss curve sits closest to the float32 oracle) timed in THIS run on the headline
+    configuration, so that one record states both builds' speed next to both builds' parity"""
+    from yolov3_tensorflow_amd import backend, ops
+    backend.set_compute_dtype('float16')
+    try:
+        for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):
+            k, v = kv.split('=')
+            ops.set_tuning(k, int(v))
+        model, loss, opt, grids = build_model(args.backbone, args.size, args.size, args.batch, args.classes, device, focal=args.focal)
+        images, labels = synthetic_batch(args.batch, args.size, args.size, args.classes, 0)
+        model.stage_batch(images, labels)
+        for _ in range(warmup):
+            model.run_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.run_step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        model.check_device_protocols()
+        return {'images_per_sec': round(args.batch * steps / dt, 2), 'ms_per_step': round(dt / steps * 1e3, 4), 'steps': steps,
+                'final_loss': round(float(model.loss_value.item()), 4)}
+    finally:
+        backend.set_compute_dtype(args.dtype)
+
+
+def cu_mask(n, pattern, total=256):
+    """8 x 32-bit words selecting n of the 256 CUs (the weight-gradient stream on CUs of its own)"""
+    bits = [0] * total
+    if pattern == 'low':
+        idx = range(n)
+    elif pattern == 'high':
+        idx = range(total - n, total)
+    elif pattern == 'even':
+        idx = [i for i in range(total) if i % (total // n) == 0][:n]
+    else:                                    # 'xcd': n / 8 low bits of every word
+        per = n // 8
+        idx = [w * 32 + b for w in range(8) for b in range(per)]
+    for i in idx:
+        bits[i] = 1
+    return [sum(bits[w * 32 + b] << b for b in range(32)) for w in range(total // 32)]
+
+
+def masked_stream(device, words):
+    """torch stream around a HIP stream created with hipExtStreamCreateWithCUMask (ctypes on the HIP runtime torch has loaded)"""
+    import ctypes as C
+    hip = C.CDLL('libamdhip64.so')
+    hip.hipExtStreamCreateWithCUMask.restype = C.c_int
+    hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    st = C.c_void_p()
+    arr = (C.c_uint32 * len(words))(*words)
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), len(words), arr)
+    if rc != 0 or not st.value:
+        raise SystemExit('hipExtStreamCreateWithCUMask failed: %d' % rc)
+    return torch.cuda.ExternalStream(st.value, device=device)
 
 
 def rccl_statement(model, world, device):
@@ -300,6 +373,11 @@ def main():
     ap.add_argument('--main-priority', type=int, default=-1, help='priority of the stream the step runs on (-1 = high, the default: its kernels are the critical '
                     'path and win CUs from the concurrent weight-gradient stream, +1 %% measured; 0 = the default stream)')
     ap.add_argument('--side-priority', type=int, default=None, help='priority of the weight-gradient stream (A/B probe)')
+    ap.add_argument('--side-cus', type=int, default=0, help='A/B probe: create the weight-gradient stream with hipExtStreamCreateWithCUMask over this many '
+                    'CUs (0 = an ordinary stream)')
+    ap.add_argument('--side-cu-pattern', default='low', choices=['low', 'high', 'even', 'xcd'], help='which CUs the mask selects: the first / last N bits, '
+                    'every other bit, or N / 8 bits of every 32-bit word (one word per XCD if the enumeration is XCD-major)')
+    ap.add_argument('--main-cus', type=int, default=0, help='A/B probe: run the main stream on a CU-masked stream over the COMPLEMENT of the side mask (1) or unmasked (0)')
     ap.add_argument('--no-sequencer', action='store_true', help='enqueue every launch from Python instead of replaying the recorded launch list')
     ap.add_argument('--no-bucket-updates', action='store_true', help='one RAdam + L2 launch after the backward pass instead of one per gradient bucket')
     ap.add_argument('--no-fused-bn', action='store_true', help='three-kernel BatchNorm backward instead of the single-launch one')
@@ -335,7 +413,17 @@ def main():
     if args.side_priority is not None:
         model.g.wgrad_stream = torch.cuda.Stream(device=device, priority=args.side_priority)
         model.g.use_side_stream(model.g.wgrad_stream)
-    if args.main_priority:
+    masked_main = None
+    if args.side_cus:
+        side_mask = cu_mask(args.side_cus, args.side_cu_pattern)
+        model.g.wgrad_stream = masked_stream(device, side_mask)
+        model.g.use_side_stream(model.g.wgrad_stream)
+        if args.main_cus:
+            masked_main = masked_stream(device, [(~w) & 0xffffffff for w in side_mask])
+    if masked_main is not None:
+        torch.cuda.synchronize(device)
+        torch.cuda.set_stream(masked_main)
+    elif args.main_priority:
         torch.cuda.synchronize(device)          # the model was built on the default stream; streams made here do not wait for it implicitly
         torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=args.main_priority))
     if args.wgrad_batch is not None:
@@ -399,7 +487,7 @@ def main():
         traffic, traffic_src = strip_hbm_traffic()
         tf = alone['strip']['rate'] / 1e12
         tf_in = instep['strip']['rate'] / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel<.., false> + conv3x3_stream_kernel<0, false> (every 3x3 stride-1 conv forward + '
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel<.., false> + conv3x3_s32_kernel<.., false> + conv3x3_stream_kernel<0, false> (every 3x3 stride-1 conv forward + '
                                                       'plain data-gradient launch, all tile variants; the forward launches of the 64-channel layers run '
                                                       'the streaming kernel: the `stream` entry; the data gradients that also carry a BatchNorm reduce are '
                                                       'the dgrad_bn entry)',
@@ -424,7 +512,7 @@ def main():
                                         'strip_launches_per_step': alone['strip_bn']['launches_per_step'],
                                         'igemm_achieved': round(alone['other_bn']['rate'] / 1e12, 2),
                                         'igemm_launches_per_step': alone['other_bn']['launches_per_step']},
-                           'wgrad': {'kernel': 'wgrad3x3_strip_kernel (3x3 stride-1 layers) / igemm_wgrad_kernel (the rest) on the weight-gradient stream; '
+                           'wgrad': {'kernel': 'wgrad9_kernel (3x3 stride-1 layers of 20 x 20 pixels and more: stationary dW tile, 128 workgroups = half the CUs, the rest stays free for the main stream) / wgrad3x3_strip_kernel (13 x 13 layers) / igemm_wgrad_kernel (the rest) on the weight-gradient stream; '
                                                'slab_sum = wgrad_reduce_batched_kernel (one launch per gradient bucket, HBM-bound)',
                                      'strip_achieved': round(alone['wgrad3x3']['rate'] / 1e12, 2),
                                      'strip_frac': round(alone['wgrad3x3']['rate'] / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -456,6 +544,12 @@ def main():
                                'MB_per_step': round(a['work_per_step'] / 1e6, 1)}
     if rank == 0:
         out['parity'] = parity_statement(args.dtype)
+        out['parity'].setdefault(args.dtype, {})['images_per_sec'] = out['value'] if world == 1 else None
+        if world == 1 and args.dtype == 'bf16' and not args.no_roofline:      # (the long form of the record: the default run; ~10 s)
+            try:
+                out['parity'].setdefault('fp16', {}).update(fp16_throughput(args, device))
+            except Exception as e:                                            # the headline number must not depend on the second build
+                out['parity'].setdefault('fp16', {})['images_per_sec_error'] = repr(e)
     if world > 1:
         out['rccl'] = rccl_statement(model, world, device)       # collective (a tiny all-gather of the per-rank view): every rank calls it
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

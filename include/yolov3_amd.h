@@ -129,6 +129,22 @@ int yolo_conv2d_dgrad_add(const yolo_conv_problem* p, const void* dy, const void
  * addend (may be NULL): the fan-in contribution is read from this buffer instead of dx (implies accumulate), see yolo_conv2d_dgrad_add.
  * yolo_conv2d_dgrad_bn_rows < 0: this problem cannot take the fused form (N*H*W*Cin >= 2^31). */
 int yolo_conv2d_dgrad_bn_rows(const yolo_conv_problem* p);
+/* Two-level partial rows (round 4): the convolution epilogues fold their per-tile rows in groups of 16-64 tiles -- the workgroup whose arrival
+ * completes a group sums that group's rows in row order (deterministic; no workgroup waits for another) -- so that the BatchNorm kernel consuming
+ * the statistics derives its constants from <= ~85 rows in its own prologue and the finalize launch between them disappears
+ * (yolo_bn_finalize_act_fwd / yolo_bn_bwd_finalize_apply take that form for large tensors).  Replaces the same tf.keras BatchNormalization
+ * statistics (basic_backbone.py:68-78) as the functions above.
+ * *_group_layout: info4 = {rows the caller allocates, ZEROED ONCE (the kernels leave their arrival counters zero after every launch), group rows
+ * P = rows [0, P) that hold the folded sums, group size (0: this problem keeps plain rows -- the RGB stem, stride-2 parity classes -- and the
+ * *_g entry point behaves like the plain one), raw rows}.  yolo_conv2d_fwd_g = yolo_conv2d_fwd for a 16-bit output with statistics;
+ * yolo_conv2d_dgrad_bn_g = yolo_conv2d_dgrad_bn; both with their rows laid out as the layout query says.  "row_group" tuning: 16 (default) / 0 / 8 / 32 / 64. */
+int yolo_conv2d_stat_group_layout(const yolo_conv_problem* p, int32_t* info4);
+int yolo_conv2d_fwd_g(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd, void* y, float* stat_sum, float* stat_sq,
+                      void* stream);
+int yolo_conv2d_dgrad_bn_group_layout(const yolo_conv_problem* p, int32_t* info4);
+int yolo_conv2d_dgrad_bn_g(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend,
+                           const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2, const float* mean2,
+                           const float* rstd2, float* partial, void* stream);
 int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend,
                          const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2,
                          const float* mean2, const float* rstd2, float* partial, void* stream);

@@ -596,7 +596,9 @@ def test_bn_act_fwd_bwd(dev, mode):
 
 
 @pytest.mark.parametrize('M,C,P,res', [(32 * 13 * 13, 512, 85, True), (32 * 26 * 26, 256, 338, False), (700, 32, 3, True), (5, 64, 1, False),
-                                        (32 * 26 * 26, 128, 169, True)], ids=str)
+                                        (32 * 26 * 26, 128, 169, True),
+                                        # (round 4: few rows + a large tensor = the streaming form that sums the rows in its own prologue)
+                                        (32 * 52 * 52, 128, 22, True), (16 * 104 * 104, 64, 43, False), (32 * 26 * 26, 256, 11, True)], ids=str)
 def test_small_map_finalize_plus_apply_in_one_launch(dev, M, C, P, res):
     """yolo_bn_finalize_act_fwd == yolo_bn_finalize + yolo_bn_act_fwd (mask variant) and yolo_bn_bwd_finalize_apply == yolo_bn_bwd_finalize +
     yolo_bn_act_bwd_apply on the same partial rows: identical activations / masks / gradients wherever the per-channel constants agree bit

@@ -283,6 +283,9 @@ def test_accumulator_statistics_plan_agrees(monkeypatch):
     images, labels = make_batch(4, H, W, 6, 7, seed=9)
     from yolov3_tensorflow_amd import engine
     res = []
+    # (plain statistics rows on the other side: the two-level rows of round 4 add the same tile sums in float32 groups first, and at random
+    # initialisation this network amplifies even that 1e-7 to ~1e-3 of the loss -- tools/probes/row_groups_diff.py -- which is not what this test is about)
+    monkeypatch.setenv('YOLO_ROW_GROUPS', '0')
     for acc in ('0', '1'):
         monkeypatch.setenv('YOLO_STAT_ACC', acc)
         model, loss, opt, grids = build('resnet-18', H, W, 4, 7, rect=-1)

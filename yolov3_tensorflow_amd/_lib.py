@@ -64,6 +64,10 @@ SIGNATURES = {
     'yolo_conv2d_fwd': (I, [CP, P, P, P, P, P, I, P, P, P]),
     'yolo_conv2d_dgrad': (I, [CP, P, P, P, I, P]),
     'yolo_conv2d_dgrad_bn_rows': (I, [CP]),
+    'yolo_conv2d_stat_group_layout': (I, [CP, P]),
+    'yolo_conv2d_fwd_g': (I, [CP, P, P, P, P, P, P, P]),
+    'yolo_conv2d_dgrad_bn_group_layout': (I, [CP, P]),
+    'yolo_conv2d_dgrad_bn_g': (I, [CP, P, P, P, I, P, P, P, P, P, P, P, P, P, P]),
     'yolo_conv2d_dgrad_bn': (I, [CP, P, P, P, I, P, P, P, P, P, P, P, P, P, P]),
     'yolo_conv2d_dgrad_bn_acc': (I, [CP, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P]),
     'yolo_conv2d_fwd_acc': (I, [CP, P, P, P, P, P, P]),

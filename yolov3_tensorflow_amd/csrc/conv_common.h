@@ -49,6 +49,10 @@ struct BnEpi {
   // exact accumulators instead of partial rows (common.h yolo_acc_*): the fused reduce adds its 2 / 3 tile sums there when `partial` is null;
   // a FORWARD launch (no fused reduce) with stat_sum == null adds its sum / sum of squares there (Q = 2)
   long long* acc;
+  // two-level partial rows: group > 0 = a row buffer holds [P = ceil(rows / group) group rows][rows raw rows][counters];
+  // the workgroup that completes a group of `group` consecutive pixel tiles folds their raw rows into the group row (conv_common.h rows_fold),
+  // so that the BatchNorm kernel that consumes the statistics sums <= ~85 rows in its own prologue and no finalize launch is needed
+  int group, rows;
 };
 struct Epi { float* ssum; float* ssq; BnEpi bn; };
 
@@ -130,6 +134,54 @@ __device__ __forceinline__ const bf16_t* gather_addr(const Gather& g, const RowI
     else          p = g.src1 + ((size_t)(r.n * g.Hs + hn) * g.Ws + wn) * g.C1 + (c - g.C0);
   }
   return p;
+}
+
+// ---- two-level partial rows ---------------------------------------------------------------------------------------------------------
+// Row buffer layout for nq quantities q[k] (separate arrays, or one array with a quantity stride), row stride rs floats:
+//   rows [0, P)          group rows, P = ceil(R / G)              (what the consumer reads)
+//   rows [P, P + R)      raw rows, one per pixel tile             (written by every workgroup with write-through stores)
+//   after row P + R of q[0]: P * tiles_n int32 arrival counters   (zero between launches: the last arriver resets its counter)
+// A workgroup (pixel tile `row`, channel tile `tile_n`, channels [n0, n0 + cols)) calls rows_fold after its raw-row stores.  The one whose
+// arrival completes its group sums the group's raw rows IN ROW ORDER -- whoever does it, the sum is the same bits: run-to-run deterministic,
+// unlike float atomics -- and stores the group row with plain stores for the NEXT kernel.  No workgroup ever waits for another one.
+// Visibility follows the cdna guide's write-through form (Guideline 16 / microarch 'Valid forms', counter row): raw rows stored with agent-scope
+// relaxed atomic stores (global_store ... sc1), every storing wave drains vmcnt(0), workgroup barrier, ONE lane adds to the counter
+// (relaxed, agent), the last arriver learns it from the value its add returned and reads the rows with sc1 loads behind a workgroup barrier.
+constexpr int YOLO_ROW_GROUP_MAX = 64;
+__host__ __device__ inline int yolo_row_groups(int R, int G) { return (R + G - 1) / G; }
+__device__ __forceinline__ void row_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int NT>
+__device__ __forceinline__ void rows_fold(float* q0, float* q1, float* q2, int nq, size_t rs, int R, int G, int row, int tile_n, int tiles_n,
+                                          int n0, int cols, int tid, int* s_flag) {
+  const int P = yolo_row_groups(R, G), grp = row / G;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's raw-row stores have left
+  __syncthreads();
+  if (tid == 0) {
+    int* cnt = reinterpret_cast<int*>(q0 + (size_t)(P + R) * rs) + grp * tiles_n + tile_n;
+    const int expect = min(G, R - grp * G);
+    const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == expect - 1 ? 1 : 0;
+    if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // self-cleaning: zero again for the next launch
+    *s_flag = last;
+  }
+  __syncthreads();
+  if (!*s_flag) return;
+  const int r0 = grp * G, nr = min(R, r0 + G) - r0;
+  for (int e = tid; e < nq * cols; e += NT) {
+    const int k = e / cols, cl = e - k * cols;
+    float* const base = (k == 0 ? q0 : (k == 1 ? q1 : q2)) + n0 + cl;
+    float t = 0.f;
+    int r = 0;
+    for (; r + 8 <= nr; r += 8) {                          // 8 loads in flight, summed in row order
+      float f[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f[u] = __hip_atomic_load(base + (size_t)(P + r0 + r + u) * rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += f[u];
+    }
+    for (; r < nr; ++r) t += __hip_atomic_load(base + (size_t)(P + r0 + r) * rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base[(size_t)grp * rs] = t;
+  }
 }
 
 // XCD-aware tile order (MI355X deals consecutive workgroups round-robin over its 8 XCDs, each with a private L2): give every XCD a
@@ -290,6 +342,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
       }
       float* red = reinterpret_cast<float*>(smem);    // [RG][BN], one quantity at a time
       const int nq = bn.y2 ? 3 : 2;
+      const bool grouped = bn.group > 0 && bn.partial;
+      const int rrow = grouped ? yolo_row_groups(bn.rows, bn.group) + prow : prow;      // (grouped: the raw row behind the group rows)
       for (int q = 0; q < nq; ++q) {
         __syncthreads();                              // the staged tile (q = 0) / the previous quantity has been read
 #pragma unroll
@@ -299,9 +353,15 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
           float t = 0.f;
 #pragma unroll 8
           for (int r = 0; r < RG; ++r) t += red[r * BN + cl];
-          if (bn.partial) bn.partial[((size_t)prow * 3 + q) * ldy + n0 + cl] = t;
+          if (grouped) row_store(bn.partial + ((size_t)rrow * 3 + q) * ldy + n0 + cl, t);
+          else if (bn.partial) bn.partial[((size_t)prow * 3 + q) * ldy + n0 + cl] = t;
           else yolo_acc_add(bn.acc, 3, ldy, prow % YOLO_ACC_NB, q, n0 + cl, t);
         }
+      }
+      if (grouped) {
+        __syncthreads();                              // (red is free: its first word takes the last-arriver flag)
+        rows_fold<NW * 64>(bn.partial, bn.partial + ldy, bn.partial + 2 * (size_t)ldy, nq, (size_t)3 * ldy, bn.rows, bn.group, prow, n0 / BN,
+                           Kout / BN, n0, BN, tid, reinterpret_cast<int*>(smem));
       }
       return;
     }
@@ -350,17 +410,27 @@ __device__ __forceinline__ void tile_epilogue(f32x4_t (&acc)[CT][PT], char* smem
         }
       }
     __syncthreads();
+    const bool grouped = bn.group > 0 && stat_sum;
     for (int cl = tid; cl < BN; cl += NW * 64) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < WMS; ++w) { s += red[w * BN + cl]; q += red[(WMS + w) * BN + cl]; }
-      if (stat_sum) {
+      if (grouped) {
+        const size_t rrow = (size_t)yolo_row_groups(bn.rows, bn.group) + tile_m;
+        row_store(stat_sum + rrow * Kout + n0 + cl, s);
+        row_store(stat_sq + rrow * Kout + n0 + cl, q);
+      } else if (stat_sum) {
         stat_sum[(size_t)tile_m * Kout + n0 + cl] = s;
         stat_sq[(size_t)tile_m * Kout + n0 + cl] = q;
       } else {
         yolo_acc_add(bn.acc, 2, Kout, tile_m % YOLO_ACC_NB, 0, n0 + cl, s);
         yolo_acc_add(bn.acc, 2, Kout, tile_m % YOLO_ACC_NB, 1, n0 + cl, q);
       }
+    }
+    if (grouped) {
+      __syncthreads();
+      rows_fold<NW * 64>(stat_sum, stat_sq, nullptr, 2, (size_t)Kout, bn.rows, bn.group, tile_m, n0 / BN, Kout / BN, n0, BN, tid,
+                         reinterpret_cast<int*>(smem));
     }
   }
 }

@@ -1089,6 +1089,22 @@ int stat_rows_for(const Gather& g, int Kout) {
   return (g.M + t.bm - 1) / t.bm;      // one partial row per pixel tile
 }
 
+// two-level partial rows (conv_common.h rows_fold): group size for R raw rows, and the rows a caller allocates for them
+int g_row_group = 16;    // "row_group" tuning: raw rows folded per group (0 = the *_g entry points keep raw rows)
+int row_group_for(const Gather& g, int R) {
+  if (g_row_group <= 0 || g.s2 || R <= 0) return 0;
+  int G = g_row_group;
+  while (G < YOLO_ROW_GROUP_MAX && (R + G - 1) / G > 64) G *= 2;      // at most ~64 group rows for the consumer's prologue
+  return G;
+}
+void row_layout(int R, int G, int K, int rs, int32_t* info) {          // {rows to allocate, group rows, group size, raw rows}
+  if (G <= 0) { info[0] = R; info[1] = R; info[2] = 0; info[3] = R; return; }
+  const int P = yolo_row_groups(R, G);
+  const long counters = (long)P * (K / 64);                            // one per (group, 64-channel tile): the narrowest channel tile of any kernel
+  info[0] = P + R + (int)((counters + rs - 1) / rs) + 1;
+  info[1] = P; info[2] = G; info[3] = R;
+}
+
 template <int BM, int BN, int NW, int WS, bool BNEPI>
 int launch_strip_ws_e(const Gather& g, const void* w, void* y, int ldy, int accumulate, const Epi& e, int Kout, hipStream_t st) {
   StripArgs a;
@@ -1212,6 +1228,8 @@ int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int l
 extern int g_fused_min_chunks;
 extern int g_ew_nt;                  // eltwise.hip
 extern int64_t g_acc_stream_elems;   // eltwise.hip
+extern int64_t g_rows_stream_elems;  // eltwise.hip
+extern int g_rows_grid;              // eltwise.hip
 extern int g_pool_scatter;
 extern int g_bwd_fin_small;     // eltwise.hip
 extern int g_reduce_cap;        // eltwise.hip
@@ -1237,6 +1255,9 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "acc_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "acc_stream_kelems"); g_acc_stream_elems = (int64_t)value * 1000; }
   else if (!strcmp(name, "bwd_fin_small")) { YOLO_CHECK_ARG(value == 0 || value == 1, "bwd_fin_small"); g_bwd_fin_small = value; }
   else if (!strcmp(name, "stream")) { YOLO_CHECK_ARG(value >= -1 && value <= 2, "stream"); g_stream = value; }
+  else if (!strcmp(name, "rows_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "rows_stream_kelems"); g_rows_stream_elems = (int64_t)value * 1000; }
+  else if (!strcmp(name, "rows_grid")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "rows_grid"); g_rows_grid = value; }
+  else if (!strcmp(name, "row_group")) { YOLO_CHECK_ARG(value == 0 || value == 8 || value == 16 || value == 32 || value == 64, "row_group"); g_row_group = value; }
   else if (!strcmp(name, "wgrad9_wgs")) { YOLO_CHECK_ARG(value >= 16 && value <= 1024, "wgrad9_wgs"); g_wgrad9_wgs = value; }
   else if (!strcmp(name, "wgrad9")) { YOLO_CHECK_ARG(value >= -1 && value <= 1, "wgrad9"); g_wgrad9 = value; }
   else if (!strcmp(name, "s32")) { YOLO_CHECK_ARG(value >= -1 && value <= 16, "s32"); g_s32 = value; }
@@ -1293,6 +1314,37 @@ extern "C" int yolo_conv2d_fwd(const yolo_conv_problem* p, const void* src0, con
   Gather g = fwd_gather(p, src0, src1);
   if (y_is_f32) return launch_fwd<true>(g, w_fwd, bias, y, p->Cout, 0, Epi{}, p->Cout, (hipStream_t)stream);
   return launch_fwd<false>(g, w_fwd, bias, y, p->Cout, 0, Epi{stat_sum, stat_sq, {}}, p->Cout, (hipStream_t)stream);
+}
+
+// Two-level statistics rows (conv_common.h rows_fold).  info4 = {rows the caller allocates (zeroed ONCE: the kernels keep the counters zero
+// between launches), group rows P the consumer reads (rows [0, P) of stat_sum / stat_sq), group size, raw rows}; group size 0 = this problem
+// keeps plain rows (the RGB stem's row-walking kernel) and yolo_conv2d_fwd_g behaves like yolo_conv2d_fwd.
+extern "C" int yolo_conv2d_stat_group_layout(const yolo_conv_problem* p, int32_t* info4) {
+  YOLO_CHECK_ARG(info4 != nullptr, "null info");
+  int rc = check_problem(p);
+  if (rc) return rc;
+  YOLO_CHECK_ARG(p->Cout % 64 == 0, "Cout must be a multiple of 64");
+  if (yolo_stem_applies(p)) { row_layout(yolo_stem_stat_rows(p), 0, p->Cout, p->Cout, info4); return YOLO_OK; }
+  static const char dummy = 0;
+  const Gather g = fwd_gather(p, &dummy, &dummy);
+  const int R = stat_rows_for(g, p->Cout);
+  row_layout(R, row_group_for(g, R), p->Cout, p->Cout, info4);
+  return YOLO_OK;
+}
+
+// yolo_conv2d_fwd (16-bit output, no bias, statistics) with the rows laid out as yolo_conv2d_stat_group_layout says
+extern "C" int yolo_conv2d_fwd_g(const yolo_conv_problem* p, const void* src0, const void* src1, const void* w_fwd, void* y, float* stat_sum,
+                                 float* stat_sq, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  YOLO_CHECK_ARG(src1 && w_fwd && y && stat_sum && stat_sq, "null pointer");
+  YOLO_CHECK_ARG(p->C0 == 0 || src0, "C0 > 0 needs src0");
+  if (yolo_stem_applies(p)) return yolo_stem_fwd(p, src1, w_fwd, y, stat_sum, stat_sq, stream);
+  Gather g = fwd_gather(p, src0, src1);
+  Epi e = {stat_sum, stat_sq, {}};
+  e.bn.rows = stat_rows_for(g, p->Cout);
+  e.bn.group = row_group_for(g, e.bn.rows);
+  return launch_fwd<false>(g, w_fwd, nullptr, y, p->Cout, 0, e, p->Cout, (hipStream_t)stream);
 }
 
 // yolo_conv2d_fwd (16-bit output, no bias) whose BatchNorm statistics go into an exact accumulator block (common.h yolo_acc_*: Q = 2,
@@ -1427,10 +1479,43 @@ extern "C" int yolo_conv2d_dgrad_bn(const yolo_conv_problem* p, const void* dy, 
   return yolo_conv2d_dgrad_bn_acc(p, dy, w_dgrad, dx, accumulate, addend, relu_mask, y, mean, rstd, y2, mean2, rstd2, partial, nullptr, stream);
 }
 
+// two-level partial rows for yolo_conv2d_dgrad_bn_g: info4 as yolo_conv2d_stat_group_layout, rows of [3][Cin] floats (stride-2 problems, whose
+// parity classes leave rows unwritten, keep plain rows: group size 0)
+extern "C" int yolo_conv2d_dgrad_bn_group_layout(const yolo_conv_problem* p, int32_t* info4) {
+  YOLO_CHECK_ARG(info4 != nullptr, "null info");
+  Gather g;
+  static const char dummy = 0;
+  int rc = dgrad_gather(p, &dummy, &g);
+  if (rc) return rc;
+  YOLO_CHECK_ARG((size_t)p->N * p->H * p->W * p->Cin < (1ull << 31), "the fused reduce addresses dx with 32-bit element offsets");
+  g.bnepi = 1;
+  const int R = (g.s2 ? 4 : 1) * stat_rows_for(g, p->Cin);
+  row_layout(R, row_group_for(g, R), p->Cin, 3 * p->Cin, info4);
+  return YOLO_OK;
+}
+
+namespace {
+int dgrad_bn_impl(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend, const void* relu_mask,
+                  const void* y, const float* mean, const float* rstd, const void* y2, const float* mean2, const float* rstd2, float* partial,
+                  int64_t* acc, bool grouped, void* stream);
+}
+extern "C" int yolo_conv2d_dgrad_bn_g(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend,
+                                      const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2,
+                                      const float* mean2, const float* rstd2, float* partial, void* stream) {
+  return dgrad_bn_impl(p, dy, w_dgrad, dx, accumulate, addend, relu_mask, y, mean, rstd, y2, mean2, rstd2, partial, nullptr, true, stream);
+}
+
 // the same with the tile sums added into an exact accumulator block (Q = 3, C = Cin; common.h yolo_acc_*) when partial is null
 extern "C" int yolo_conv2d_dgrad_bn_acc(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend,
                                         const void* relu_mask, const void* y, const float* mean, const float* rstd, const void* y2,
                                         const float* mean2, const float* rstd2, float* partial, int64_t* acc, void* stream) {
+  return dgrad_bn_impl(p, dy, w_dgrad, dx, accumulate, addend, relu_mask, y, mean, rstd, y2, mean2, rstd2, partial, acc, false, stream);
+}
+
+namespace {
+int dgrad_bn_impl(const yolo_conv_problem* p, const void* dy, const void* w_dgrad, void* dx, int accumulate, const void* addend, const void* relu_mask,
+                  const void* y, const float* mean, const float* rstd, const void* y2, const float* mean2, const float* rstd2, float* partial,
+                  int64_t* acc, bool grouped, void* stream) {
   YOLO_CHECK_ARG(dy && w_dgrad && dx, "null pointer");
   YOLO_CHECK_ARG(y && mean && rstd && ((partial != nullptr) != (acc != nullptr)), "the fused reduce needs y, mean, rstd and either partial rows or an accumulator block");
   YOLO_CHECK_ARG(!y2 || (mean2 && rstd2), "y2 needs mean2 and rstd2");
@@ -1446,9 +1531,14 @@ extern "C" int yolo_conv2d_dgrad_bn_acc(const yolo_conv_problem* p, const void* 
   e.bn.partial = partial;
   e.bn.acc = (long long*)acc;
   e.bn.addend = (const bf16_t*)addend;             // non-null: the fan-in source instead of dx itself (implies accumulate)
+  if (grouped && partial) {
+    e.bn.rows = stat_rows_for(g, p->Cin);
+    e.bn.group = row_group_for(g, e.bn.rows);
+  }
   YOLO_CHECK_ARG(accumulate != 2 || (g.s2 && g.s2_ny == 4 && !addend), "accumulate = 2 needs the parity-class data gradient and no addend");
   return launch_fwd<false>(g, w_dgrad, nullptr, dx, p->Cin, accumulate == 2 ? 2 : ((accumulate || addend) ? 1 : 0), e, p->Cin, (hipStream_t)stream);
 }
+}  // namespace
 
 namespace {
 struct WgradPlan { Gather g; int bco, tiles_k, tiles_c, split_k, sps; bool strip, w9; };

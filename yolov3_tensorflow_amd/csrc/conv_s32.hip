@@ -390,6 +390,8 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
   if (nq == 0) return;
   float* const red = reinterpret_cast<float*>(smem);  // [RG][BN], one quantity at a time
   static_assert(RG * BN * 4 <= BM * OLD, "reduction scratch");
+  const bool grouped = bn.group > 0 && (BNEPI ? bn.partial != nullptr : stat_sum != nullptr);       // two-level partial rows (conv_common.h rows_fold)
+  const size_t rrow = grouped ? (size_t)yolo_row_groups(bn.rows, bn.group) + tile_m : (size_t)tile_m;
   for (int q = 0; q < nq; ++q) {
     __syncthreads();                                  // the staged tile (q = 0) / the previous quantity has been read
 #pragma unroll
@@ -400,13 +402,21 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
 #pragma unroll 8
       for (int r = 0; r < RG; ++r) t += red[r * BN + cl];
       if constexpr (BNEPI) {
-        if (bn.partial) bn.partial[((size_t)tile_m * 3 + q) * ldy + n0 + cl] = t;
+        if (grouped) row_store(bn.partial + (rrow * 3 + q) * ldy + n0 + cl, t);
+        else if (bn.partial) bn.partial[((size_t)tile_m * 3 + q) * ldy + n0 + cl] = t;
         else yolo_acc_add(bn.acc, 3, ldy, tile_m % YOLO_ACC_NB, q, n0 + cl, t);
       } else {
-        if (stat_sum) (q == 0 ? stat_sum : stat_sq)[(size_t)tile_m * Kout + n0 + cl] = t;
+        if (grouped) row_store((q == 0 ? stat_sum : stat_sq) + rrow * Kout + n0 + cl, t);
+        else if (stat_sum) (q == 0 ? stat_sum : stat_sq)[(size_t)tile_m * Kout + n0 + cl] = t;
         else yolo_acc_add(bn.acc, 2, Kout, tile_m % YOLO_ACC_NB, q, n0 + cl, t);
       }
     }
+  }
+  if (grouped) {
+    __syncthreads();
+    if constexpr (BNEPI) rows_fold<NT>(bn.partial, bn.partial + ldy, bn.partial + 2 * (size_t)ldy, nq, (size_t)3 * ldy, bn.rows, bn.group, tile_m,
+                                       tile_n, tiles_n, n0, BN, tid, reinterpret_cast<int*>(smem));
+    else rows_fold<NT>(stat_sum, stat_sq, nullptr, 2, (size_t)Kout, bn.rows, bn.group, tile_m, tile_n, tiles_n, n0, BN, tid, reinterpret_cast<int*>(smem));
   }
 }
 

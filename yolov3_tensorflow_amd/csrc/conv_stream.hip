@@ -391,18 +391,28 @@ __global__ __launch_bounds__(512) void conv3x3_stream_kernel(StreamArgs a, void*
     }
   }
   __syncthreads();
+  const bool grouped = bn.group > 0 && (BNEPI ? bn.partial != nullptr : stat_sum != nullptr);       // two-level partial rows (conv_common.h rows_fold)
+  const size_t rrow = grouped ? (size_t)yolo_row_groups(bn.rows, bn.group) + wg_m : (size_t)wg_m;
   if (tid < nq * 64) {
     const int q = tid >> 6, cl = tid & 63;
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) t += red2[(q * 8 + w) * 64 + cl];
     if constexpr (BNEPI) {
-      if (bn.partial) bn.partial[((size_t)wg_m * 3 + q) * ldy + n0 + cl] = t;
+      if (grouped) row_store(bn.partial + (rrow * 3 + q) * ldy + n0 + cl, t);
+      else if (bn.partial) bn.partial[((size_t)wg_m * 3 + q) * ldy + n0 + cl] = t;
       else yolo_acc_add(bn.acc, 3, ldy, wg_m % YOLO_ACC_NB, q, n0 + cl, t);
     } else {
-      if (stat_sum) (q == 0 ? stat_sum : stat_sq)[(size_t)wg_m * Kout + n0 + cl] = t;
+      if (grouped) row_store((q == 0 ? stat_sum : stat_sq) + rrow * Kout + n0 + cl, t);
+      else if (stat_sum) (q == 0 ? stat_sum : stat_sq)[(size_t)wg_m * Kout + n0 + cl] = t;
       else yolo_acc_add(bn.acc, 2, Kout, wg_m % YOLO_ACC_NB, q, n0 + cl, t);
     }
+  }
+  if (grouped) {
+    __syncthreads();
+    if constexpr (BNEPI) rows_fold<512>(bn.partial, bn.partial + ldy, bn.partial + 2 * (size_t)ldy, nq, (size_t)3 * ldy, bn.rows, bn.group, wg_m,
+                                        tile_n, a.ny, n0, 64, tid, reinterpret_cast<int*>(smem));
+    else rows_fold<512>(stat_sum, stat_sq, nullptr, 2, (size_t)Kout, bn.rows, bn.group, wg_m, tile_n, a.ny, n0, 64, tid, reinterpret_cast<int*>(smem));
   }
   ST_STAMP(42);
 }

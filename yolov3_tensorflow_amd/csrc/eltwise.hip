@@ -447,6 +447,218 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_acc_kernel(const long
   }
 }
 
+// ---- finalize from <= 128 partial ROWS inside the streaming apply kernels (round 4: two-level partial rows, conv_common.h rows_fold) ----------
+// The convolution epilogues fold their per-tile rows in groups, so a BatchNorm unit's statistics arrive as P <= ~85 rows whatever the layer
+// size.  Every 256-thread workgroup of the streaming kernel sums them for all C channels itself -- 256 / C row lanes per channel, 8 loads in
+// flight per lane, lanes combined in LDS in a fixed order (double) -- ~1.5 us of prologue that all workgroups pay at the same time, and the
+// finalize launch (5 us alone, 5-10 us in the step, 46 of them per step) is gone.  Workgroup 0 publishes what the backward pass / the moving
+// averages need.  The grid is half the plain kernels' (the prologue's L2 traffic scales with it); the streaming loop is unrolled by two instead.
+template <int K>
+__device__ __forceinline__ void rows_column_totals(const float* const (&src)[K], int P, size_t rs, int C, double* s_part, double* s_tot) {
+  // s_part [RL][K][min(C, 256)] doubles, s_tot [K][C] doubles
+  const int tid = threadIdx.x;
+  if (C <= EW_THREADS) {
+    const int RL = EW_THREADS / C, rl = tid / C, c = tid - rl * C;
+    double t[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) t[k] = 0.0;
+    int p0 = rl;
+    for (; p0 + 7 * RL < P; p0 += 8 * RL) {
+      float f[K][8];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f[k][u] = src[k][(size_t)(p0 + u * RL) * rs + c];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[k] += (double)f[k][u];
+    }
+    for (; p0 < P; p0 += RL) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) t[k] += (double)src[k][(size_t)p0 * rs + c];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) s_part[(rl * K + k) * C + c] = t[k];
+    __syncthreads();
+    if (tid < C) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double a = 0.0;
+        for (int r = 0; r < RL; ++r) a += s_part[(r * K + k) * C + tid];
+        s_tot[k * C + tid] = a;
+      }
+    }
+  } else {
+    for (int c = tid; c < C; c += EW_THREADS) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        double a = 0.0;
+        for (int p0 = 0; p0 < P; ++p0) a += (double)src[k][(size_t)p0 * rs + c];
+        s_tot[k * C + c] = a;
+      }
+    }
+  }
+  __syncthreads();
+}
+inline size_t rows_kernel_lds(int K, int C) { return (size_t)(EW_THREADS * K + K * C) * sizeof(double) + 2 * (size_t)C * sizeof(float); }
+
+__global__ __launch_bounds__(EW_THREADS) void bn_act_fwd_rows_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int P, size_t rs,
+                                                                     float count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float eps, float momentum, float* __restrict__ moving_mean,
+                                                                     float* __restrict__ moving_var, float* __restrict__ scale_o,
+                                                                     float* __restrict__ shift_o, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                                     const bf16_t* __restrict__ y, const bf16_t* __restrict__ res,
+                                                                     bf16_t* __restrict__ out, size_t nchunks, int C, int relu,
+                                                                     uint8_t* __restrict__ mask, int nt) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  double* const s_part = reinterpret_cast<double*>(s_raw);
+  double* const s_tot = s_part + EW_THREADS * 2;
+  float* const s_const = reinterpret_cast<float*>(s_tot + 2 * C);      // [2][C]
+  const float* const src[2] = {psum, psq};
+  rows_column_totals<2>(src, P, rs, C, s_part, s_tot);
+  for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+    const double mean = s_tot[c] / (double)count;
+    double var = s_tot[C + c] / (double)count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd, sh = beta[c] - (float)mean * sc;
+    s_const[c] = sc;
+    s_const[C + c] = sh;
+    if (blockIdx.x == 0) {
+      scale_o[c] = sc;
+      shift_o[c] = sh;
+      mean_o[c] = (float)mean;
+      rstd_o[c] = rstd;
+      if (moving_mean) {
+        const double unb = count > 1.f ? var * ((double)count / ((double)count - 1.0)) : var;
+        moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
+        moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unb;
+      }
+    }
+  }
+  __syncthreads();
+  const int CV = C >> 3;
+  const int c = (int)(((size_t)blockIdx.x * EW_THREADS + threadIdx.x) % CV) * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = s_const[c + j]; sh[j] = s_const[C + c + j]; }
+  const size_t stride = (size_t)gridDim.x * EW_THREADS;
+  auto one = [&](size_t i, const uint4& yv, const uint4& rv) {
+    float v[8];
+    unpack_bf8(yv, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+    if (res) {
+      float r[8];
+      unpack_bf8(rv, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    if (relu) {
+      if (mask) {
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m |= (v[j] > 0.f ? 1u : 0u) << j;
+        mask[i] = (uint8_t)m;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st16(out + i * 8, pack_bf8(v));
+  };
+  size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  for (; i + stride < nchunks; i += 2 * stride) {      // two chunks per iteration: all four reads in flight before the first use
+    const uint4 y0 = ld16s(y + i * 8, nt & 2), y1 = ld16s(y + (i + stride) * 8, nt & 2);
+    uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;
+    if (res) { r0 = ld16(res + i * 8); r1 = ld16(res + (i + stride) * 8); }
+    one(i, y0, r0);
+    one(i + stride, y1, r1);
+  }
+  if (i < nchunks) {
+    const uint4 y0 = ld16s(y + i * 8, nt & 2);
+    uint4 r0 = make_uint4(0u, 0u, 0u, 0u);
+    if (res) r0 = ld16(res + i * 8);
+    one(i, y0, r0);
+  }
+}
+
+// backward twin: dgamma / dbeta / k1 / k2 from the rows the data gradient's epilogue left ([P][3][C], quantities 0 and 1), then
+// dy (=|+=) a (g - k1 - xhat k2) and the optional shortcut copy dres (=|+=) g, g = the masked gradient
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_rows_kernel(const float* __restrict__ partial, int P, size_t rs, size_t qs, float count,
+                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                       float* __restrict__ k1_o, float* __restrict__ k2_o,
+                                                                       const bf16_t* __restrict__ gin, const bf16_t* __restrict__ y,
+                                                                       const float* __restrict__ a1, const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd, bf16_t* __restrict__ dy, int acc_dy,
+                                                                       bf16_t* __restrict__ dres, int acc_dres, size_t nchunks, int C, int nt) {
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  double* const s_part = reinterpret_cast<double*>(s_raw);
+  double* const s_tot = s_part + EW_THREADS * 2;
+  float* const s_const = reinterpret_cast<float*>(s_tot + 2 * C);      // [2][C]
+  const float* const src[2] = {partial, partial + qs};
+  rows_column_totals<2>(src, P, rs, C, s_part, s_tot);
+  for (int c = threadIdx.x; c < C; c += EW_THREADS) {
+    const double t0 = s_tot[c], t1 = s_tot[C + c];
+    const float v1 = (float)(t0 / (double)count), v2 = (float)(t1 / (double)count);
+    s_const[c] = v1;
+    s_const[C + c] = v2;
+    if (blockIdx.x == 0) {
+      if (dgamma) dgamma[c] = (float)t1;
+      if (dbeta) dbeta[c] = (float)t0;
+      k1_o[c] = v1;
+      k2_o[c] = v2;
+    }
+  }
+  __syncthreads();
+  const int CV = C >> 3;
+  const int c = (int)(((size_t)blockIdx.x * EW_THREADS + threadIdx.x) % CV) * 8;
+  float ca[8], cmu[8], crs[8], ck1[8], ck2[8];
+  ld8f(a1 + c, ca); ld8f(mean + c, cmu); ld8f(rstd + c, crs);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ck1[j] = s_const[c + j]; ck2[j] = s_const[C + c + j]; }
+  const size_t stride = (size_t)gridDim.x * EW_THREADS;
+  auto one = [&](size_t i, const uint4& gv, const uint4& yv, const uint4& ov, const uint4& rv) {
+    float g[8], v[8], o[8];
+    unpack_bf8(gv, g);
+    unpack_bf8(yv, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = ca[j] * (g[j] - ck1[j] - (v[j] - cmu[j]) * crs[j] * ck2[j]);
+    if (acc_dy) {
+      unpack_bf8(ov, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += v[j];
+    }
+    st16(dy + i * 8, pack_bf8(o));
+    if (dres) {
+      if (acc_dres) {
+        unpack_bf8(rv, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += v[j];
+      }
+      st16(dres + i * 8, pack_bf8(g));
+    }
+  };
+  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+  size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  for (; i + stride < nchunks; i += 2 * stride) {
+    const size_t i1 = i + stride;
+    const uint4 g0 = ld16s(gin + i * 8, nt & 1), y0 = ld16s(y + i * 8, nt & 1), g1 = ld16s(gin + i1 * 8, nt & 1), y1 = ld16s(y + i1 * 8, nt & 1);
+    uint4 o0 = z4, o1 = z4, r0 = z4, r1 = z4;
+    if (acc_dy) { o0 = ld16(dy + i * 8); o1 = ld16(dy + i1 * 8); }
+    if (dres && acc_dres) { r0 = ld16(dres + i * 8); r1 = ld16(dres + i1 * 8); }
+    one(i, g0, y0, o0, r0);
+    one(i1, g1, y1, o1, r1);
+  }
+  if (i < nchunks) {
+    const uint4 g0 = ld16s(gin + i * 8, nt & 1), y0 = ld16s(y + i * 8, nt & 1);
+    uint4 o0 = z4, r0 = z4;
+    if (acc_dy) o0 = ld16(dy + i * 8);
+    if (dres && acc_dres) r0 = ld16(dres + i * 8);
+    one(i, g0, y0, o0, r0);
+  }
+}
+
 // ---- small maps: finalize + apply in ONE launch -------------------------------------------------------------------------------------
 // On the 13 x 13 / 26 x 26 maps both launches of a BatchNorm (finalize: a few hundred partial rows; apply: a few MB) are nothing but the
 // ~5 us floor of a dependent launch.  Here a 1024-thread workgroup owns FM_CG channels and a slice of the rows: it first reduces the
@@ -1576,6 +1788,13 @@ extern "C" int yolo_bn_bwd_finalize_grouped(const float* partial, int P, int64_t
   return YOLO_OK;
 }
 
+int64_t g_rows_stream_elems = 2000000;  // "rows_stream_kelems" tuning (x1000): tensors from this many elements take the streaming finalize-from-rows kernels
+int g_rows_grid = 1024;                 // "rows_grid": workgroups of those kernels (their prologues' L2 traffic scales with it)
+namespace {
+// the streaming form pays P x C x 8 bytes of prologue reads in EVERY workgroup: only where that is a few tens of KB (two-level rows: <= ~85 rows
+// of 64 channels ... 6 rows of 512); 85 raw rows of 512 channels (13 x 13 maps without row groups) stay on the one-workgroup-per-CU merged kernel
+inline bool rows_stream_ok(int P, int C, int64_t M) { return P <= 128 && (int64_t)P * C <= 8192 && M * (int64_t)C >= g_rows_stream_elems && chan_ok(C); }
+inline int rows_grid(size_t items) { size_t b = (items + 2 * EW_THREADS - 1) / (2 * EW_THREADS); if (b > (size_t)g_rows_grid) b = g_rows_grid; return b < 1 ? 1 : (int)b; } }
 int64_t g_acc_stream_elems = 2000000;   // "acc_stream_kelems" tuning (x1000): tensors from this many elements take the streaming accumulator kernels
 namespace {
 // row slices of the merged small-map launches: ~256 workgroups in all, at least 256 rows each
@@ -1596,6 +1815,14 @@ extern "C" int yolo_bn_finalize_act_fwd(const float* psum, const float* psq, int
   YOLO_CHECK_ARG(P > 0 && C > 0 && C % FM_CG == 0 && count > 0.f && M > 0 && M * (int64_t)C < (int64_t)1 << 31, "bad size (C must be a multiple of 32)");
   YOLO_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "moving_mean and moving_var go together");
   YOLO_CHECK_ARG(!relu_mask || relu, "relu_mask needs relu");
+  if (rows_stream_ok(P, C, M)) {     // large tensor, few rows: the streaming kernel sums them in its prologue
+    const size_t nch = (size_t)M * (C / 8);
+    hipLaunchKernelGGL(bn_act_fwd_rows_kernel, dim3(rows_grid(nch)), dim3(EW_THREADS), rows_kernel_lds(2, C), (hipStream_t)stream, psum, psq, P,
+                       (size_t)row_stride, count, gamma, beta, eps, momentum, moving_mean, moving_var, scale, shift, mean, rstd, (const bf16_t*)y,
+                       (const bf16_t*)res, (bf16_t*)out, nch, C, relu, relu_mask, g_ew_nt);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+  }
   const int ms = fm_slices(M, C);
   const int rows_per = (int)((M + ms - 1) / ms);
   hipLaunchKernelGGL(bn_finalize_act_kernel<false>, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, psum, psq, P, (size_t)row_stride, C, count,
@@ -1651,6 +1878,14 @@ extern "C" int yolo_bn_bwd_finalize_apply(const float* partial, int P, int64_t r
   YOLO_CHECK_ARG(partial && k1 && k2 && g && y && a1 && mean && rstd && dy, "null pointer");
   YOLO_CHECK_ARG(P > 0 && C > 0 && C % FM_CG == 0 && count > 0.f && M > 0 && M * (int64_t)C < (int64_t)1 << 31, "bad size (C must be a multiple of 32)");
   YOLO_CHECK_ARG(q_stride >= C && row_stride >= 2 * q_stride, "bad strides");
+  if (rows_stream_ok(P, C, M)) {
+    const size_t nch = (size_t)M * (C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3(rows_grid(nch)), dim3(EW_THREADS), rows_kernel_lds(2, C), (hipStream_t)stream, partial, P,
+                       (size_t)row_stride, (size_t)q_stride, count, dgamma, dbeta, k1, k2, (const bf16_t*)g, (const bf16_t*)y, a1, mean, rstd,
+                       (bf16_t*)dy, acc_dy, (bf16_t*)dres, acc_dres, nch, C, g_ew_nt);
+    YOLO_LAUNCH_CHECK();
+    return YOLO_OK;
+  }
   const int ms = fm_slices(M, C);
   const int rows_per = (int)((M + ms - 1) / ms);
   hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<false>, dim3(C / FM_CG, ms), dim3(1024), 0, (hipStream_t)stream, partial, P, (size_t)row_stride,

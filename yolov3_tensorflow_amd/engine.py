@@ -209,6 +209,13 @@ class Graph(object):
         self.stat_acc = os.environ.get('YOLO_STAT_ACC', '0') != '0'
         self.acc_max_elems = int(float(os.environ.get('YOLO_ACC_MAX_ELEMS', '6e6')))
         self.acc_buf = None
+        # two-level partial rows (round 4; ops.conv2d_stat_group_layout, conv_common.h rows_fold): the convolution epilogues fold their per-tile
+        # statistics rows in groups of 16-64 tiles, every unit then has <= ~85 rows, and its finalize + apply run as ONE launch (the streaming
+        # form of ops.bn_finalize_act_fwd / ops.bn_bwd_finalize_apply sums the rows in its prologue).  Built, bit-exact and deterministic
+        # (tests/test_row_groups_gpu.py), measured and OFF: 23 of the 46 finalize launches go and the BatchNorm kernels take 80 us less per step,
+        # but every workgroup of every convolution now drains its stores and waits for a returning device-scope atomic before it leaves its CU
+        # -- 3-9 us per launch, +205 us per step: 7.90 k against 8.13 k images/s (profiles/r04_row_groups_ab_*).  YOLO_ROW_GROUPS=1 turns it on.
+        self.row_groups = os.environ.get('YOLO_ROW_GROUPS', '0') != '0'
         self.fin_merge_rows = int(os.environ.get('YOLO_FIN_MERGE_ROWS', '128'))
         self.fin_merge_bwd_rows = int(os.environ.get('YOLO_FIN_MERGE_BWD_ROWS', str(self.fin_merge_rows)))
         self.vals = []
@@ -273,7 +280,10 @@ class Graph(object):
         y = Val(self, 'conv', (N, p.Ho, p.Wo, cout_dev), x=x, wp=wp, bp=bp, p=p, f32=use_bias, filters=filters)
         y.cell = self._buffer(y.shape, torch.float32 if use_bias else backend.torch_dtype())
         y.dy_cell = self._buffer(y.shape, backend.torch_dtype())
-        y.stat_rows = ops.conv2d_stat_rows(p)
+        lay = ops.conv2d_stat_group_layout(p) if (self.row_groups and not use_bias) else None
+        y.stat_grouped = bool(lay and lay['group'] > 0)
+        y.stat_rows = lay['alloc_rows'] if y.stat_grouped else ops.conv2d_stat_rows(p)       # rows of the buffer (zeroed once: arrival counters live in it)
+        y.stat_groups = lay['groups'] if y.stat_grouped else y.stat_rows                     # rows the BatchNorm kernels read
         y.stat_cell = None if use_bias else self._buffer((2, y.stat_rows, cout_dev), torch.float32)
         y.wants_stats = False
         self.tape.append(ConvOp(self, y))
@@ -753,7 +763,7 @@ class ConvOp(object):
             st = y.stat_cell['t']
             self.ssum, self.ssq = st[0], st[1]
             C = y.shape[3]
-            y.stats = (st[0].view(-1), st[1].view(-1), y.stat_rows, C)        # (psum, psq, P, row_stride)
+            y.stats = (st[0].view(-1), st[1].view(-1), y.stat_groups, C)      # (psum, psq, P, row_stride)
         x = y.x
         if x.kind == 'cat':
             self.src0, self.src1 = x.a.src, x.b
@@ -776,6 +786,10 @@ class ConvOp(object):
         acc = getattr(y, 'acc_fwd', None)
         if acc is not None and self.g.training:          # statistics into the unit's accumulator block (Graph.plan_accumulators)
             ops.conv2d_fwd(y.p, self.src1.buf, self.w, y.buf, src0=None if self.src0 is None else self.src0.buf, stat_acc=acc)
+            return
+        if self.ssum is not None and y.stat_grouped:
+            ops.conv2d_fwd(y.p, self.src1.buf, self.w, y.buf, src0=None if self.src0 is None else self.src0.buf, stat_sum=self.ssum,
+                           stat_sq=self.ssq, grouped=True)
             return
         ops.conv2d_fwd(y.p, self.src1.buf, self.w, y.buf, src0=None if self.src0 is None else self.src0.buf, bias=self.bias,
                        stat_sum=self.ssum, stat_sq=self.ssq)
@@ -1025,9 +1039,11 @@ class ApplyOp(object):
         if rows <= 0:
             return
         y1, b1, y2, b2 = self._reduce_operands()
-        self.frows = rows
-        self.fpartial = torch.zeros(rows, 3, self.C, device=self.g.dev)     # rows a launch does not write stay zero
-        conv.bn_epi = dict(mask=self.mask, y=y1.buf, mean=b1.mean, rstd=b1.rstd, partial=self.fpartial)
+        lay = ops.conv2d_dgrad_bn_group_layout(conv.y.p) if self.g.row_groups else None
+        grouped = bool(lay and lay['group'] > 0)
+        self.frows = lay['groups'] if grouped else rows
+        self.fpartial = torch.zeros(lay['alloc_rows'] if grouped else rows, 3, self.C, device=self.g.dev)     # rows a launch does not write stay zero
+        conv.bn_epi = dict(mask=self.mask, y=y1.buf, mean=b1.mean, rstd=b1.rstd, partial=self.fpartial, grouped=grouped)
         if b2 is not None:
             conv.bn_epi.update(y2=y2.buf, mean2=b2.mean, rstd2=b2.rstd)
         self.producer = conv

@@ -84,13 +84,18 @@ def zero_words(t):
     check(_lib.load().yolo_zero_words(_p(t), t.numel(), _stream()), 'yolo_zero_words')
 
 
-def conv2d_fwd(p, src1, w_fwd, y, src0=None, bias=None, stat_sum=None, stat_sq=None, stat_acc=None):
-    """``stat_acc``: an exact accumulator block (acc_words(2, Cout) int64, zeroed this step) that receives the BatchNorm statistics instead
+def conv2d_fwd(p, src1, w_fwd, y, src0=None, bias=None, stat_sum=None, stat_sq=None, stat_acc=None, grouped=False):
+    """``grouped``: the statistics rows are laid out as conv2d_stat_group_layout says (two-level rows, yolo_conv2d_fwd_g).  ``stat_acc``: an exact accumulator block (acc_words(2, Cout) int64, zeroed this step) that receives the BatchNorm statistics instead
     of the per-tile rows stat_sum / stat_sq (yolo_conv2d_fwd_acc)"""
     if stat_acc is not None:
         if bias is not None or stat_sum is not None or y.dtype == torch.float32:
             raise ValueError('stat_acc goes with a 16-bit output, no bias and no statistics rows')
         check(_lib.load().yolo_conv2d_fwd_acc(C.byref(p), _p(src0), _p(src1), _p(w_fwd), _p(y), _p(stat_acc), _stream()), 'yolo_conv2d_fwd_acc')
+        return
+    if grouped:
+        if bias is not None or stat_sum is None or y.dtype == torch.float32:
+            raise ValueError('grouped statistics rows go with a 16-bit output, no bias and statistics')
+        check(_lib.load().yolo_conv2d_fwd_g(C.byref(p), _p(src0), _p(src1), _p(w_fwd), _p(y), _p(stat_sum), _p(stat_sq), _stream()), 'yolo_conv2d_fwd_g')
         return
     check(_lib.load().yolo_conv2d_fwd(C.byref(p), _p(src0), _p(src1), _p(w_fwd), _p(bias), _p(y),
                                       1 if y.dtype == torch.float32 else 0, _p(stat_sum), _p(stat_sq), _stream()), 'yolo_conv2d_fwd')
@@ -117,9 +122,25 @@ def conv2d_dgrad(p, dy, w_dgrad, dx, accumulate=False, bn=None, addend=None, eve
                                                    _p(bn['y']), _p(bn['mean']), _p(bn['rstd']), _p(bn.get('y2')), _p(bn.get('mean2')),
                                                    _p(bn.get('rstd2')), None, _p(bn['acc']), _stream()), 'yolo_conv2d_dgrad_bn_acc')
         return
-    check(_lib.load().yolo_conv2d_dgrad_bn(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _p(addend), _p(bn.get('mask')), _p(bn['y']),
-                                           _p(bn['mean']), _p(bn['rstd']), _p(bn.get('y2')), _p(bn.get('mean2')), _p(bn.get('rstd2')),
-                                           _p(bn['partial']), _stream()), 'yolo_conv2d_dgrad_bn')
+    fn, name = (_lib.load().yolo_conv2d_dgrad_bn_g, 'yolo_conv2d_dgrad_bn_g') if bn.get('grouped') else (_lib.load().yolo_conv2d_dgrad_bn, 'yolo_conv2d_dgrad_bn')
+    check(fn(C.byref(p), _p(dy), _p(w_dgrad), _p(dx), int(accumulate), _p(addend), _p(bn.get('mask')), _p(bn['y']),
+             _p(bn['mean']), _p(bn['rstd']), _p(bn.get('y2')), _p(bn.get('mean2')), _p(bn.get('rstd2')), _p(bn['partial']), _stream()), name)
+
+
+def _layout(fn, p, name):
+    info = (C.c_int32 * 4)()
+    check(fn(C.byref(p), info), name)
+    return dict(alloc_rows=int(info[0]), groups=int(info[1]), group=int(info[2]), raw_rows=int(info[3]))
+
+
+def conv2d_stat_group_layout(p):
+    """two-level statistics rows of conv2d_fwd(grouped=True): dict(alloc_rows, groups, group, raw_rows) (yolo_conv2d_stat_group_layout)"""
+    return _layout(_lib.load().yolo_conv2d_stat_group_layout, p, 'yolo_conv2d_stat_group_layout')
+
+
+def conv2d_dgrad_bn_group_layout(p):
+    """the same for the [rows][3][Cin] partial buffer of conv2d_dgrad(bn=..., grouped=True)"""
+    return _layout(_lib.load().yolo_conv2d_dgrad_bn_group_layout, p, 'yolo_conv2d_dgrad_bn_group_layout')
 
 
 def conv2d_dgrad_classed(p):
