@@ -92,9 +92,12 @@ int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info8);
  * yolo_conv2d_stat_rows and yolo_conv2d_dgrad_bn_rows); "bwd_fin_small": 0 (default) / 1 yolo_bn_bwd_finalize on 1024- or 256-thread workgroups (bit-identical results);
  * "s32": -1 (default) the automatic rule of the 32x32x16 strip kernel (conv_s32.hip: 3x3 stride-1 layers below 80 columns; it yields while "strip_bm" is not -1) / 0 never /
  * 1 + id force tile configuration id (0: 128 x 128, 1: 256 x 64, 2: 128 x 64 K split 2, 3: 64 x 128 K split 2, 4: 64 x 64 K split 4, 5: 256 x 128 on 8 waves, 6: 128 x 128 on 8 waves
- * K split 2, 7: 256 x 64 on 8 waves K split 2) where it fits (changes yolo_conv2d_stat_rows and yolo_conv2d_dgrad_bn_rows);
+ * K split 2, 7: 256 x 64 on 8 waves K split 2, 8: 384 x 128 on 8 waves with 96 x 64 wave tiles) where it fits (changes yolo_conv2d_stat_rows and yolo_conv2d_dgrad_bn_rows);
  * "wgrad9": -1 (default) the stationary-output weight gradient (conv_wgrad9.hip) for 3x3 stride-1 layers of 20 x 20 pixels and more / 0 never / 1 wherever it
  * fits (changes yolo_conv2d_wgrad_splits and the slab sizes: re-plan);
+ * "wgrad9_wgs": workgroups of that kernel's grid (16..1024, default 128: one workgroup per CU on half the CUs, the other half stays free for the main stream);
+ * "reduce_wgs": 0 (default: one workgroup per table block) or the most workgroups of yolo_wgrad_reduce_batched, "opt_wgs": the most workgroups (16..2048,
+ * default 2048) of the optimizer / cast launches -- both measured as CU partitions for the side stream (profiles/r04_side_grid_caps_ab.txt: no gain);
  * "ew_nt": bit mask, default 3: non-temporal loads of the streamed-once operands of the BatchNorm backward (1) / forward (2) apply kernels;
  * "acc_stream_kelems": tensors from this many thousand elements take the streaming form of the accumulator-fed BatchNorm launches;
  * "strip_ws": 0 auto / 2 / 3 weight-ring stages; "s2_classes": 0 / 1 stride-2 data gradient as four dense parity classes;

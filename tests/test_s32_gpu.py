@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = {0: (128, 128), 1: (256, 64), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 128), 6: (128, 128), 7: (256, 64)}
+CONFIGS = {0: (128, 128), 1: (256, 64), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 128), 6: (128, 128), 7: (256, 64), 8: (384, 128)}
 
 
 @pytest.fixture(scope='module')

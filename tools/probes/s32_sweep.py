@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from yolov3_tensorflow_amd import ops, backend
 
 dev = torch.device('cuda:0')
-cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else '0,1,2,3,4,5,6,7').split(',')]
+cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else '0,1,2,3,4,5,6,7,8').split(',')]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ACT = backend.torch_dtype()
 LAYERS = [  # name, N, H, W, Cin, Cout

@@ -910,38 +910,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restr
 // arena until its bucket is complete, then one grid sums them all -- 31 small launches per step (each 4-70 us, mostly ramp and tail)
 // become 3.  tab[e] = {first float4 of dW in `grads`, first float4 of the slabs in `arena`, float4s per slab, slabs, first workgroup}.
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const long long* __restrict__ tab, int n, const float4* __restrict__ arena,
-                                                                   float4* __restrict__ grads) {
+                                                                   float4* __restrict__ grads, int total_blocks) {
   __shared__ float4 red[256];
-  int e = 0;
-  for (int k = 1; k < n; ++k) e = ((long long)blockIdx.x >= tab[k * 5 + 4]) ? k : e;      // n <= a few dozen, uniform: scalar loads
-  const long long dst4 = tab[e * 5], src4 = tab[e * 5 + 1], n4 = tab[e * 5 + 2];
-  const int nslab = (int)tab[e * 5 + 3];
-  // a workgroup covers 64 float4 columns with 4 slab lanes, or -- layers with many slabs (YOLO_REDUCE_WIDE_SLABS and more: small layers
-  // split over hundreds of pixel ranges, the stem's per-workgroup slabs) -- 16 columns with 16 lanes: 4x the loads in flight per column
-  const bool wide = nslab >= YOLO_REDUCE_WIDE_SLABS;
-  const int ncol = wide ? 16 : 64, nl = wide ? 16 : 4;
-  const int col = threadIdx.x % ncol, grp = threadIdx.x / ncol;
-  const long long i = ((long long)blockIdx.x - tab[e * 5 + 4]) * ncol + col;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < n4) {
-    const float4* p = arena + src4 + i;
-    int z = grp;
-    for (; z + 3 * nl < nslab; z += 4 * nl) {
-      const float4 a = p[(size_t)z * n4], b = p[(size_t)(z + nl) * n4], c = p[(size_t)(z + 2 * nl) * n4], d = p[(size_t)(z + 3 * nl) * n4];
-      s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
-      s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+  // the grid may be smaller than the table's block count ("reduce_wgs" tuning): a workgroup then walks blocks b, b + grid, ... -- the same
+  // sums block by block, but a launch that leaves compute units free for the kernels of the other stream
+  for (long long vb = blockIdx.x; vb < total_blocks; vb += gridDim.x) {
+    int e = 0;
+    for (int k = 1; k < n; ++k) e = (vb >= tab[k * 5 + 4]) ? k : e;      // n <= a few dozen, uniform: scalar loads
+    const long long dst4 = tab[e * 5], src4 = tab[e * 5 + 1], n4 = tab[e * 5 + 2];
+    const int nslab = (int)tab[e * 5 + 3];
+    // a workgroup covers 64 float4 columns with 4 slab lanes, or -- layers with many slabs (YOLO_REDUCE_WIDE_SLABS and more: small layers
+    // split over hundreds of pixel ranges, the stem's per-workgroup slabs) -- 16 columns with 16 lanes: 4x the loads in flight per column
+    const bool wide = nslab >= YOLO_REDUCE_WIDE_SLABS;
+    const int ncol = wide ? 16 : 64, nl = wide ? 16 : 4;
+    const int col = threadIdx.x % ncol, grp = threadIdx.x / ncol;
+    const long long i = (vb - tab[e * 5 + 4]) * ncol + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      const float4* p = arena + src4 + i;
+      int z = grp;
+      for (; z + 3 * nl < nslab; z += 4 * nl) {
+        const float4 a = p[(size_t)z * n4], b = p[(size_t)(z + nl) * n4], c = p[(size_t)(z + 2 * nl) * n4], d = p[(size_t)(z + 3 * nl) * n4];
+        s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+        s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+      }
+      for (; z < nslab; z += nl) {
+        const float4 a = p[(size_t)z * n4];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      }
     }
-    for (; z < nslab; z += nl) {
-      const float4 a = p[(size_t)z * n4];
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    red[grp * ncol + col] = s;
+    __syncthreads();
+    if (grp == 0 && i < n4) {
+      float4 r = red[col];
+      for (int k = 1; k < nl; ++k) { const float4 o = red[k * ncol + col]; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+      grads[dst4 + i] = r;
     }
-  }
-  red[grp * ncol + col] = s;
-  __syncthreads();
-  if (grp == 0 && i < n4) {
-    float4 r = red[col];
-    for (int k = 1; k < nl; ++k) { const float4 o = red[k * ncol + col]; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
-    grads[dst4 + i] = r;
+    __syncthreads();      // (red is rewritten by the next block)
   }
 }
 
@@ -1090,6 +1095,7 @@ int stat_rows_for(const Gather& g, int Kout) {
 }
 
 // two-level partial rows (conv_common.h rows_fold): group size for R raw rows, and the rows a caller allocates for them
+int g_reduce_wgs = 0;    // "reduce_wgs" tuning: most workgroups of the batched slab sum (0 = one per table block)
 int g_row_group = 16;    // "row_group" tuning: raw rows folded per group (0 = the *_g entry points keep raw rows)
 int row_group_for(const Gather& g, int R) {
   if (g_row_group <= 0 || g.s2 || R <= 0) return 0;
@@ -1234,6 +1240,7 @@ extern int g_pool_scatter;
 extern int g_bwd_fin_small;     // eltwise.hip
 extern int g_reduce_cap;        // eltwise.hip
 extern int g_fused_small_chunks;   // eltwise.hip
+extern int g_opt_wgs;              // optim.hip
 
 extern "C" int yolo_set_tuning(const char* name, int value) {
   YOLO_CHECK_ARG(name != nullptr, "null name");
@@ -1258,6 +1265,8 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "rows_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "rows_stream_kelems"); g_rows_stream_elems = (int64_t)value * 1000; }
   else if (!strcmp(name, "rows_grid")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "rows_grid"); g_rows_grid = value; }
   else if (!strcmp(name, "row_group")) { YOLO_CHECK_ARG(value == 0 || value == 8 || value == 16 || value == 32 || value == 64, "row_group"); g_row_group = value; }
+  else if (!strcmp(name, "reduce_wgs")) { YOLO_CHECK_ARG(value == 0 || (value >= 16 && value <= 65536), "reduce_wgs"); g_reduce_wgs = value; }
+  else if (!strcmp(name, "opt_wgs")) { YOLO_CHECK_ARG(value >= 16 && value <= 2048, "opt_wgs"); g_opt_wgs = value; }
   else if (!strcmp(name, "wgrad9_wgs")) { YOLO_CHECK_ARG(value >= 16 && value <= 1024, "wgrad9_wgs"); g_wgrad9_wgs = value; }
   else if (!strcmp(name, "wgrad9")) { YOLO_CHECK_ARG(value >= -1 && value <= 1, "wgrad9"); g_wgrad9 = value; }
   else if (!strcmp(name, "s32")) { YOLO_CHECK_ARG(value >= -1 && value <= 16, "s32"); g_s32 = value; }
@@ -1720,8 +1729,9 @@ extern "C" int yolo_conv2d_wgrad_slabs(const yolo_conv_problem* p, const void* s
 extern "C" int yolo_wgrad_reduce_batched(const int64_t* table_dev, int nentries, int total_blocks, const float* arena, float* grads, void* stream) {
   YOLO_CHECK_ARG(table_dev && arena && grads && nentries > 0 && total_blocks > 0, "bad argument");
   YOLO_CHECK_ARG((reinterpret_cast<uintptr_t>(arena) & 15) == 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0, "arena / grads must be 16-byte aligned");
-  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)table_dev, nentries,
-                     (const float4*)arena, (float4*)grads);
+  const int grid = (g_reduce_wgs > 0 && total_blocks > g_reduce_wgs) ? g_reduce_wgs : total_blocks;
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long long*)table_dev, nentries,
+                     (const float4*)arena, (float4*)grads, total_blocks);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------------------
   constexpr int OLD = BN * 2 + 16;                    // staged row stride in bytes (16-byte pad: conflict-free 16-byte writes)
-  constexpr int CPR = BN / 8, RG = NT / CPR, ITER = (BM + RG - 1) / RG, NB = ITER < 4 ? ITER : 4;
+  constexpr int CPR = BN / 8, RG = NT / CPR, ITER = (BM + RG - 1) / RG, NB = ITER <= 4 ? ITER : (ITER <= 8 ? 4 : (ITER + 1) / 2);
   static_assert(NT % CPR == 0, "row-walk geometry");
   const int e_ch = tid % CPR, e_rg = tid / CPR, e_c = n0 + e_ch * 8;
   bf16_t* const Y = reinterpret_cast<bf16_t*>(Yv);
@@ -432,6 +432,7 @@ constexpr S32Cfg kCfg[] = {
     {4, 2, 1, 2, 2},   // 5: 256 x 128, 8 waves
     {2, 2, 2, 2, 2},   // 6: 128 x 128, 8 waves, K split 2
     {4, 1, 2, 2, 2},   // 7: 256 x 64, 8 waves, K split 2
+    {4, 2, 1, 3, 2},   // 8: 384 x 128, 8 waves (96 x 64 wave tiles)
 };
 constexpr int kNCfg = (int)(sizeof(kCfg) / sizeof(kCfg[0]));
 
@@ -538,6 +539,7 @@ int yolo_s32_launch(const yoloconv::Gather& g, const void* w, void* y, int ldy, 
     case 5: return s32_launch_c<4, 2, 1, 2, 2>(g, w, y, ldy, accumulate, e, Kout, st);
     case 6: return s32_launch_c<2, 2, 2, 2, 2>(g, w, y, ldy, accumulate, e, Kout, st);
     case 7: return s32_launch_c<4, 1, 2, 2, 2>(g, w, y, ldy, accumulate, e, Kout, st);
+    case 8: return s32_launch_c<4, 2, 1, 3, 2>(g, w, y, ldy, accumulate, e, Kout, st);
   }
   yolo_set_error("%s:%d: bad s32 configuration", __FILE__, __LINE__);
   return YOLO_ERR_INVALID_ARG;

@@ -137,9 +137,13 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   }
 }
 
+}  // namespace
+int g_opt_wgs = 2048;      // "opt_wgs" tuning: most workgroups of the optimizer / cast launches (grid-stride loops)
+namespace {
+
 inline int opt_grid(size_t n4) {
   size_t b = (n4 + OPT_THREADS - 1) / OPT_THREADS;
-  if (b > 2048) b = 2048;
+  if (b > (size_t)g_opt_wgs) b = (size_t)g_opt_wgs;
   if (b < 1) b = 1;
   return (int)b;
 }
