@@ -42,12 +42,18 @@ const char* yolo_last_error(void);
  * items [begin, end) with one call (the host cost of a step drops from ~2.8 ms of Python + ctypes to the bare HIP launches).
  * yolo_seq_mark() = number of items recorded so far (segment boundary for host work that must happen between launches, e.g. a collective).
  * yolo_seq_fork(a, b): stream b waits for everything queued on stream a at this point (event record + stream wait; usable outside a
- * recording too).  One recording at a time, single-threaded; the caller re-records when any buffer address or launch decision changes.
+ * recording too).  yolo_seq_fork_local(a, b): the same edge for the case where ONLY kernels of this device wait behind it (main <->
+ * weight-gradient stream): its event is created with hipEventDisableSystemFence -- the kernels' own agent-scope release / acquire make
+ * their stores visible to each other, the system-scope writeback of a default event record is for copy engines, peers and the host
+ * (+1.1 % on the step, profiles/r04_fork_fence_ab.txt; env YOLO_FORK_FENCE=system | device selects the default / device-scope event).
+ * Use yolo_seq_fork in front of anything that is not a kernel of this device (a collective, a copy).
+ * One recording at a time, single-threaded; the caller re-records when any buffer address or launch decision changes.
  * ------------------------------------------------------------------------------------------------------------------ */
 int yolo_seq_begin(void);                 /* -> sequence id */
 int yolo_seq_mark(void);
 int yolo_seq_end(void);                   /* -> number of items */
 int yolo_seq_fork(void* from_stream, void* to_stream);
+int yolo_seq_fork_local(void* from_stream, void* to_stream);
 int yolo_seq_run(int seq, int begin, int end);
 int yolo_seq_free(int seq);
 /* CRC-32C (Castagnoli) of a host buffer, continuing from `seed` (0 to start): the checksum of the TensorFlow checkpoint files the

@@ -56,6 +56,7 @@ SIGNATURES = {
     'yolo_seq_mark': (I, []),
     'yolo_seq_end': (I, []),
     'yolo_seq_fork': (I, [P, P]),
+    'yolo_seq_fork_local': (I, [P, P]),
     'yolo_seq_run': (I, [I, I, I]),
     'yolo_seq_free': (I, [I]),
     'yolo_conv2d_stat_rows': (I, [CP]),

@@ -129,9 +129,11 @@ class DeviceImagePipeline(object):
                 self._alloc_stage(slot, int(total * 1.25))
                 slot.dev = torch.empty(slot.stage.numel(), dtype=torch.uint8, device=self.device)
                 slot.alloc_stream = torch.cuda.current_stream(self.device)
-                if slot.desc_host is None:
-                    slot.desc_host = torch.empty(self.N * ctypes.sizeof(self.lib.ImageDesc), dtype=torch.uint8).pin_memory()
-                    slot.desc_dev = torch.empty_like(slot.desc_host, device=self.device)
+        if slot.desc_host is None:                  # (not under the branch above: reserve() may have sized the staging buffers already)
+            with torch.cuda.device(self.device):
+                slot.desc_host = torch.empty(self.N * ctypes.sizeof(self.lib.ImageDesc), dtype=torch.uint8).pin_memory()
+                slot.desc_dev = torch.empty_like(slot.desc_host, device=self.device)
+                slot.alloc_stream = torch.cuda.current_stream(self.device)
         stage = slot.stage.numpy()
         slot.descs, slot.total = descs, total
         slot.offsets = [int(descs[n].offset) for n in range(self.N)]

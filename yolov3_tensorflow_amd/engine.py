@@ -566,7 +566,7 @@ class Graph(object):
         side = self.wgrad_stream
         if self._repack_event is not None:        # the data-gradient weight copies were refreshed on the side stream (refresh_dgrad_async)
             if side is not None:
-                self.stream_wait(torch.cuda.current_stream(self.dev), side)
+                self.stream_wait(torch.cuda.current_stream(self.dev), side, local=True)
             self._repack_event = None
         cuts = {cut: (lo, self.ps.n if hi is None else hi) for cut, lo, hi in self.buckets}
         for i, f in enumerate(self.bwd):
@@ -575,7 +575,7 @@ class Graph(object):
                 self.bucket_done(*cuts[i])
         self.bucket_done(*self.bucket_ranges[-1], last=True)
         if side is not None and not self.tail_on_main:
-            self.stream_wait(torch.cuda.current_stream(self.dev), side)
+            self.stream_wait(torch.cuda.current_stream(self.dev), side, local=True)
 
     def plan_accumulators(self):
         """exact accumulator blocks (one flat int64 buffer, zeroed by ONE launch at the start of every step) for the BatchNorm units whose
@@ -606,13 +606,15 @@ class Graph(object):
                 op.producer.bn_epi = dict(op.producer.bn_epi, acc=op.acc_b, partial=None)
         self.fwd.insert(0, lambda: ops.zero_words(self.acc_buf))
 
-    def stream_wait(self, waiter, signaler):
+    def stream_wait(self, waiter, signaler, local=False):
         """``waiter`` (a torch stream) waits for everything queued on ``signaler`` so far.  Eager mode goes through the library
-        (yolo_seq_fork) so that the edge becomes part of a recorded launch sequence; under hipGraph capture torch's own event does it"""
+        (yolo_seq_fork) so that the edge becomes part of a recorded launch sequence; under hipGraph capture torch's own event does it.
+        ``local``: what waits behind the edge are kernels of this device only (main <-> weight-gradient stream): yolo_seq_fork_local, an
+        event without the system-scope writeback.  Edges in front of a collective (copy engines, peers, the host read) keep the default."""
         if self.capturing:
             waiter.wait_stream(signaler)
         else:
-            ops.stream_fork(signaler, waiter)
+            ops.stream_fork(signaler, waiter, local=local)
 
     def reduce_slabs(self, lo, hi):
         tab, n, blocks = self.reduce_tables[(lo, hi)]
@@ -629,7 +631,7 @@ class Graph(object):
         cross-stream hand-off at the end of the step instead of two (each costs 10-20 us of idle GPU on this runtime)"""
         if last and self.tail_on_main and self.wgrad_stream is not None:
             self.flush_wgrad()
-            self.stream_wait(torch.cuda.current_stream(self.dev), self.wgrad_stream)
+            self.stream_wait(torch.cuda.current_stream(self.dev), self.wgrad_stream, local=True)
             self.reduce_slabs(lo, hi)
             if self.on_bucket is not None:
                 self.on_bucket(lo, hi, True)
@@ -702,7 +704,7 @@ class Graph(object):
             for fn in pending:
                 fn()
             return
-        self.stream_wait(side, torch.cuda.current_stream(self.dev))
+        self.stream_wait(side, torch.cuda.current_stream(self.dev), local=True)
         with torch.cuda.stream(side):
             for fn in pending:
                 fn()

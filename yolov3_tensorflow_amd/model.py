@@ -236,7 +236,7 @@ class YOLOv3Model(object):
                     if self._comm_stream is not None and dp:
                         g.stream_wait(main, self._comm_stream)
                     if g.wgrad_stream is not None and not tail:     # (tail: the main stream joined the side stream before the last range)
-                        g.stream_wait(main, g.wgrad_stream)
+                        g.stream_wait(main, g.wgrad_stream, local=True)
                     if probe is not None:
                         e1 = torch.cuda.Event(enable_timing=True)
                         e1.record(main)

@@ -525,9 +525,12 @@ def sum_partials(partial, n, add, out, out_plain=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------- launch sequencer
-def stream_fork(from_stream, to_stream):
-    """``to_stream`` waits for everything queued on ``from_stream`` so far (torch streams); recorded when a sequence is being recorded"""
-    check(_lib.load().yolo_seq_fork(C.c_void_p(from_stream.cuda_stream), C.c_void_p(to_stream.cuda_stream)), 'yolo_seq_fork')
+def stream_fork(from_stream, to_stream, local=False):
+    """``to_stream`` waits for everything queued on ``from_stream`` so far (torch streams); recorded when a sequence is being recorded.
+    ``local``: only kernels of this device wait behind the edge (yolo_seq_fork_local: no system-scope writeback at the event record)"""
+    lib = _lib.load()
+    fn, name = (lib.yolo_seq_fork_local, 'yolo_seq_fork_local') if local else (lib.yolo_seq_fork, 'yolo_seq_fork')
+    check(fn(C.c_void_p(from_stream.cuda_stream), C.c_void_p(to_stream.cuda_stream)), name)
 
 
 def seq_begin():
