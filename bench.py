@@ -368,7 +368,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'], help='16-bit compute type: bf16 (default) or fp16 (libyolov3_amd_fp16.so + '
                     'static loss scaling; BASELINE.json configs[4])')
     ap.add_argument('--focal', action='store_true', help='focal loss on (BASELINE.json configs[4])')
-    ap.add_argument('--wgrad-batch', type=int, default=None, help='weight gradients per hand-off to the side stream (engine default 4)')
+    ap.add_argument('--wgrad-batch', type=int, default=None, help='weight gradients per hand-off to the side stream (engine default 2)')
     ap.add_argument('--wgrad-gflop', type=float, default=None, help='also hand over when the pending weight gradients reach this many GFLOP')
     ap.add_argument('--main-priority', type=int, default=-1, help='priority of the stream the step runs on (-1 = high, the default: its kernels are the critical '
                     'path and win CUs from the concurrent weight-gradient stream, +1 %% measured; 0 = the default stream)')

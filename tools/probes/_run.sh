@@ -1,13 +1,10 @@
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-out=gpurun_out/r4y
+out=gpurun_out/r5b
 rm -rf $out && mkdir -p $out
-timeout -k 10 600 python -m pytest tests/test_parallel_gpu.py -x -q > $out/test_par.log 2>&1; rc=$?; echo "pytest rc $rc" >> $out/test_par.log
-tail -3 $out/test_par.log
-[ $rc -eq 0 ] || exit 1
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q --deselect tests/test_parallel_gpu.py > $out/test.log 2>&1; rc=$?; echo "pytest rc $rc" >> $out/test.log
-tail -5 $out/test.log
-[ $rc -eq 0 ] || exit 1
-timeout -k 10 300 python tools/loss_curve.py --out $out/r04_loss_curve_config1.json > $out/lc_bf16.log 2>&1 && tail -3 $out/lc_bf16.log &&
-timeout -k 10 300 python tools/loss_curve.py --dtype float16 --out $out/r04_loss_curve_config1_fp16.json > $out/lc_fp16.log 2>&1 && tail -3 $out/lc_fp16.log
+for t in "0 lead_grid=1024" "1 lead_grid=2048" "1 lead_grid=512" "1 lead_grid=256" "0 lead_grid=1024" "1 lead_grid=1024"; do
+  set -- $t
+  YOLO_LEAD_FIN=$1 YOLO_TUNE=$2 timeout -k 10 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline > $out/b.json 2>$out/b.err || { echo FAILED; tail -5 $out/b.err; exit 1; }
+  python -c "import json; d=json.loads(open('$out/b.json').read().strip().splitlines()[-1]); print('lead_fin %-18s  %8.1f img/s  %.4f ms  loss %s' % ('$t', d['value'], d['ms_per_step'], d['config']['final_loss']))" | tee -a $out/ab.txt
+done

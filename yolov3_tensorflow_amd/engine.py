@@ -228,7 +228,8 @@ class Graph(object):
         self._alloc = []
         self._repack_table = None
         self.wgrad_stream = None
-        self.wgrad_batch = 4               # at most this many weight gradients per main->side stream hand-off (see on_wgrad_stream)
+        self.wgrad_batch = 2               # at most this many weight gradients per main->side stream hand-off (see on_wgrad_stream; with the
+                                           # fence-free local edges 2 measures +0.5 % over 4, 1 is -0.3 %: profiles/r04_wgrad_batch_ab.txt)
         self._wgrad_pending = []
         self._wgrad_cost, self.wgrad_cost_limit = 0.0, 18.0   # ... or as soon as the pending ones reach this many GFLOP (a big 3x3 layer goes alone)
         self.bucket_cut, self.bucket_offset, self.on_bucket = -1, 0, None
