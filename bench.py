@@ -176,7 +176,7 @@ def strip_hbm_traffic():
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_hbm_traffic.json')))
     for path in reversed(files):
         try:
-            rows = [k for k in json.load(open(path))['kernels'] if k['kernel'].startswith(('conv3x3_strip_kernel', 'conv3x3_stream_kernel'))]
+            rows = [k for k in json.load(open(path))['kernels'] if k['kernel'].startswith(('conv3x3_strip_kernel', 'conv3x3_stream_kernel', 'conv3x3_s32_kernel'))]
             n = sum(k['launches'] for k in rows)
             if n:
                 b = sum((k['fetch_corrected_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024.0 * k['launches'] for k in rows) / n
