@@ -707,7 +707,7 @@ __device__ __forceinline__ void group_reduce(const float* const (&src)[K], int P
 }
 
 // (ACC: the statistics come from an exact accumulator block -- common.h yolo_acc_*, written by yolo_conv2d_fwd_acc -- passed in `psum`:
-// 16 buckets to sum whatever the number of pixel tiles, so the merged launch serves every layer size)
+// YOLO_ACC_NB (8) buckets to sum whatever the number of pixel tiles, so the merged launch serves every layer size)
 template <bool ACC>
 __global__ __launch_bounds__(1024) void bn_finalize_act_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int P,
                                                                size_t rstride, int C, float count, const float* __restrict__ gamma,
