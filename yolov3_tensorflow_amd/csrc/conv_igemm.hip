@@ -929,13 +929,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const long lo
     if (i < n4) {
       const float4* p = arena + src4 + i;
       int z = grp;
+      // (slabs are read exactly once: non-temporal loads keep them from displacing the L2 lines of the convolution running beside this launch)
+      auto ldslab = [&](int zz) {
+        typedef float f32x4nt_t __attribute__((ext_vector_type(4)));
+        const f32x4nt_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt_t*>(p + (size_t)zz * n4));
+        return make_float4(v.x, v.y, v.z, v.w);
+      };
       for (; z + 3 * nl < nslab; z += 4 * nl) {
-        const float4 a = p[(size_t)z * n4], b = p[(size_t)(z + nl) * n4], c = p[(size_t)(z + 2 * nl) * n4], d = p[(size_t)(z + 3 * nl) * n4];
+        const float4 a = ldslab(z), b = ldslab(z + nl), c = ldslab(z + 2 * nl), d = ldslab(z + 3 * nl);
         s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
         s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
       }
       for (; z < nslab; z += nl) {
-        const float4 a = p[(size_t)z * n4];
+        const float4 a = ldslab(z);
         s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
       }
     }
