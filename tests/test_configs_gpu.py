@@ -166,7 +166,7 @@ def test_native_launch_sequencer_replays_the_step_bit_exactly():
         if native:
             assert model._seq is not None and len(model._seq[2]) == 1 and model._seq[2][0][0] > 150       # one segment: the whole step
             sid = model._seq[0]
-            model.g.wgrad_batch = 2                      # a launch decision changes: the stale recording is dropped, the step re-recorded
+            model.g.wgrad_batch = 3                      # a launch decision changes: the stale recording is dropped, the step re-recorded
             model.train_on_batch(*batches[0])
             assert model._seq is not None and model._seq[0] != sid
         else:
