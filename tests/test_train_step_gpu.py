@@ -179,7 +179,8 @@ def test_forward_loss_grads_and_step(backbone, rect, compute_dtype, focal):
     for n_, e, nr in errs:
         print('   %-40s %.4f |ref| %.3e' % (n_, e, nr))
     worst = max(errs, key=lambda t: t[1])
-    assert worst[1] < 5e-2, worst
+    # measured over the nine cases (round 4): bf16 1.1-1.6 % (16-bit activation gradients with an 8-bit mantissa), fp16 0.14-0.17 %
+    assert worst[1] < (4e-3 if half else 2.5e-2), worst
 
     # ---- optimizer step: weights after one RAdam+L2 update vs the oracle step (same gradients path) ----
     model._update()
