@@ -126,6 +126,14 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(Wg9Args a, float* __restric
     return ok ? off : OOB;
   };
   const unsigned xrowb = (unsigned)(a.Cin * 2), yrowb = (unsigned)(a.Cout * 2);
+  // Most pieces lie inside one image row, clear of the pad column: then the lane's offset is a scalar (the base pixel) times the row size plus a
+  // loop-invariant per-lane constant -- one VALU add instead of the ~22 of lane_off.  The condition is wave-uniform (the cursor lives in scalar
+  // registers).
+  const unsigned xlane = (unsigned)lrow * xrowb + xcol, ylane = (unsigned)lrow * yrowb + ycol;
+  auto piece_off = [&](const Cur& c, unsigned rowbytes, unsigned col, unsigned lane_const) {
+    if ((c.x + 7 < a.W) & (c.y < a.H) & ((unsigned)c.n < (unsigned)a.N)) return (unsigned)c.m * rowbytes + lane_const;
+    return lane_off(c, rowbytes, col);
+  };
 
   // ---- prologue: X pieces [0, (2 D + 128) / 8) = positions [Q0 - D, Q0 + D + 128) (they do not wrap: 2 D + 128 <= R), dY stages 0 and 1
   const int npro = (2 * a.D + 128) >> 3;
@@ -216,14 +224,14 @@ __global__ __launch_bounds__(512) void wgrad9_kernel(Wg9Args a, float* __restric
     load_raw(r1, yb + 4096, xb);
     __builtin_amdgcn_sched_barrier(0);
     const bool more = s + 2 < nst;
-    const unsigned offx = more ? lane_off(cx, xrowb, xcol) : OOB;          // (past the range: zeros into rows nobody reads; same vmcnt arithmetic)
+    const unsigned offx = more ? piece_off(cx, xrowb, xcol, xlane) : OOB;          // (past the range: zeros into rows nobody reads; same vmcnt arithmetic)
     const bf16x8_t a0 = frag_y(r0);
     mfma_row(a0, r0, 0);
     __builtin_amdgcn_sched_barrier(0);
     w9_dma(rX, xrow * 128, offx);
     if (xrow == 0) w9_dma(rX, RB, offx);
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned offy = more ? lane_off(cy, yrowb, ycol) : OOB;
+    const unsigned offy = more ? piece_off(cy, yrowb, ycol, ylane) : OOB;
     mfma_row(a0, r0, 1);
     __builtin_amdgcn_sched_barrier(0);
     {
