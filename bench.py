@@ -201,6 +201,9 @@ def parity_statement(dtype):
             d = json.load(open(files[-1]))['float32_oracle']
             out[key] = {'max': round(d['max'], 6), 'median': round(d['median'], 6), 'within_1e-3': '%d/%d' % (d['steps_within_1e-3'], len(d['relative_deviation'])),
                         'source': 'profiles/' + os.path.basename(files[-1])}
+            if d.get('assignment_differs'):       # steps on which the GPU run and the oracle assign a ground truth to different (head, anchor) pairs
+                out[key]['assignment_differs_at_steps'] = d['assignment_differs']
+                out[key]['max_on_the_other_steps'] = round(d['max_same_assignment'], 6)
         except (KeyError, ValueError, OSError):
             continue
     out['holds_1e-3_on_every_step'] = [k for k in ('bf16', 'fp16') if k in out and out[k]['within_1e-3'].split('/')[0] == out[k]['within_1e-3'].split('/')[1]]

@@ -407,8 +407,9 @@ def test_stride2_dgrad_parity_classes_match_strided_gather(dev, shape):
         got = run()
     finally:
         ops.set_tuning('s2_classes', 1)
-    for a, b in zip(got, ref):       # same products, different summation order: within a bf16 ulp
-        torch.testing.assert_close(a, b, rtol=2 ** -7, atol=2e-3)
+    # same products, different summation order: within a bf16 ulp (of the GRADIENT term where base + gradient cancels: |dgrad| <= 4)
+    torch.testing.assert_close(got[0], ref[0], rtol=2 ** -7, atol=2e-3)
+    torch.testing.assert_close(got[1], ref[1], rtol=2 ** -6, atol=2 ** -6)
 
 
 @pytest.mark.parametrize('shape', [(2, 52, 52, 64, 128), (3, 26, 30, 128, 256), (1, 27, 25, 64, 64)], ids=str)

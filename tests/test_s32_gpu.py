@@ -167,3 +167,77 @@ def test_s32_dgrad_with_bn_reduce_epilogue(dev, cfg, case):
     torch.testing.assert_close(got[1], (gd * ((yd - mean.double()) * rstd.double())).sum(0), rtol=1e-4, atol=1e-5 * max(scale, 1.0))
     if has2:
         torch.testing.assert_close(got[2], (gd * ((y2.double() - mean2.double()) * rstd2.double())).sum(0), rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize('shape', [
+    # N, H, W (input of the stride-2 convolution = dX grid), Cin, Cout
+    (2, 104, 104, 64, 128),     # conv2d_6 of the benchmark model (one 64-channel block per class)
+    (3, 52, 52, 128, 256),      # conv2d_11: two blocks per class, four slices
+    (5, 26, 26, 256, 512),      # conv2d_16: the 128 x 64 K-split configuration
+    (3, 12, 20, 64, 128),       # small map: image boundaries and row wraps inside every strip
+    (2, 80, 80, 64, 128), (2, 40, 40, 128, 256), (2, 20, 20, 256, 512),      # BASELINE.json configs[0] (320 x 320, batch 2)
+    (1, 2, 2, 64, 64),          # one pixel per class: every tap but (0, 0) is padding
+], ids=str)
+def test_s32_stride2_classes_match_implicit_gemm(dev, dtype, shape):
+    """the stride-2 data gradient's four parity classes on conv3x3_s32_kernel (MODE 1: "s32_s2" = 1, the default) against the implicit-GEMM
+    class kernel ("s32_s2" = 0) and a float32 reference: plain, accumulating, onto the even / even class only (accumulate = 2), and with the
+    fused BatchNorm-backward reduce (masked gradient bit-identical to mask(plain), tile sums against double)"""
+    from yolov3_tensorflow_amd import ops
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    p = ops.conv_problem(N, H, W, Cin, Cout, 3, 2, 'same')
+    assert ops.conv2d_dgrad_classed(p)
+    w = bf(torch.randn(Cout, 3, 3, Cin, generator=g) * (1.0 / math.sqrt(9 * Cout / 4))).to(dev)
+    w_dg = torch.empty(Cin, 3, 3, Cout, dtype=ACT(), device=dev)
+    ops.repack_dgrad_weights(w, w_dg, Cout, 3, 3, Cin)
+    dy = bf(torch.randn(N, p.Ho, p.Wo, Cout, generator=g)).to(dev)
+    base = bf(torch.randn(N, H, W, Cin, generator=g)).to(dev)
+    M = N * H * W
+    y = bf(torch.randn(M, Cin, generator=g) * 1.3 + 0.2).to(dev)
+    mean, rstd = (torch.randn(Cin, generator=g) * 0.2).to(dev), (torch.rand(Cin, generator=g) + 0.5).to(dev)
+    mask = torch.randint(0, 256, (M * Cin // 8,), generator=g, dtype=torch.uint8).to(dev)
+
+    def run(expect_s32):
+        rows = ops.conv2d_dgrad_bn_rows(p)
+        dx = torch.full((N, H, W, Cin), float('nan'), dtype=ACT(), device=dev)
+        ops.conv2d_dgrad(p, dy, w_dg, dx)
+        acc = base.clone()
+        ops.conv2d_dgrad(p, dy, w_dg, acc, accumulate=True)
+        ee = base.clone()
+        ops.conv2d_dgrad(p, dy, w_dg, ee, accumulate=2)
+        part = torch.zeros(rows, 3, Cin, device=dev)
+        fused = base.clone()
+        ops.conv2d_dgrad(p, dy, w_dg, fused, accumulate=2, bn=dict(mask=mask, y=y, mean=mean, rstd=rstd, partial=part))
+        torch.cuda.synchronize()
+        return dx.float().cpu(), acc.float().cpu(), ee.float().cpu(), fused.float().cpu(), part.double().sum(0).cpu(), rows
+
+    try:
+        ops.set_tuning('s32_s2', 0)
+        ref = run(False)
+        ops.set_tuning('s32_s2', 1)
+        got = run(True)
+    finally:
+        ops.set_tuning('s32_s2', 1)
+    bm = 256 if N * p.Ho * p.Wo >= 16384 else 128
+    assert got[5] == 4 * ((N * p.Ho * p.Wo + bm - 1) // bm)          # (the s32 plan took the problem: one row per class and pixel tile)
+    torch.testing.assert_close(got[0], ref[0], rtol=2 ** -7, atol=2e-3)
+    torch.testing.assert_close(got[1], ref[1], rtol=2 ** -6, atol=2 ** -6)
+    torch.testing.assert_close(got[2], ref[2], rtol=2 ** -6, atol=2 ** -6)
+    # accumulate = 2: the even / even class adds onto the buffer, the other three overwrite it
+    ee = got[2].clone()
+    assert torch.equal(ee[:, 1::2], got[0][:, 1::2]) and torch.equal(ee[:, ::2, 1::2], got[0][:, ::2, 1::2])
+    # float32 reference: conv_transpose of the stride-2 convolution (TF SAME on an even map pads bottom / right only)
+    x_ref = torch.zeros(N, Cin, H + 1, W + 1, requires_grad=True)
+    y_ref = F.conv2d(x_ref, w.float().cpu().permute(0, 3, 1, 2), stride=2)
+    assert y_ref.shape[2:] == (p.Ho, p.Wo)
+    y_ref.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    torch.testing.assert_close(got[0], x_ref.grad[:, :, :H, :W].permute(0, 2, 3, 1), rtol=1e-2, atol=1e-2)
+    # fused reduce: the masked gradient is mask(accumulate = 2 result) bit for bit; sums against double
+    want = got[2].reshape(M, Cin // 8, 8)
+    bits = ((mask.cpu().to(torch.int32).reshape(M, Cin // 8, 1) >> torch.arange(8, dtype=torch.int32)) & 1).float()
+    want = (want * bits).reshape(M, Cin)
+    assert torch.equal(got[3].reshape(M, Cin), want)
+    gd, yd = want.double(), y.double().cpu()
+    scale = max(float(gd.abs().sum(0).max()), 1.0)
+    torch.testing.assert_close(got[4][0], gd.sum(0), rtol=1e-5, atol=1e-6 * scale)
+    torch.testing.assert_close(got[4][1], (gd * ((yd - mean.double().cpu()) * rstd.double().cpu())).sum(0), rtol=1e-4, atol=1e-5 * scale)

@@ -26,6 +26,10 @@ def run(steps=20, plateau_after=10, dtype='bfloat16', with_emulating_oracle=True
     from oracle.train import OracleTrainer
     backend.set_compute_dtype(dtype)
     try:
+        from yolov3_tensorflow_amd import ops as _ops
+        for kv in filter(None, os.environ.get('YOLO_TUNE', '').split(',')):      # kernel-selection overrides (A/B runs), applied to this dtype's library
+            k, v = kv.split('=')
+            _ops.set_tuning(k, int(v))
         images, labels = load_fixture()
         H = W = 320
         N, Cn = 2, 13
@@ -48,15 +52,19 @@ def run(steps=20, plateau_after=10, dtype='bfloat16', with_emulating_oracle=True
             o.set_weights(model.get_weights())
             orc[tag] = o
         gpu, ref = [], {t: [] for t in orc}
+        shift = {t: [] for t in orc}      # largest per-head difference of the xy term, relative to the loss (see "assignment" below)
         for step in range(steps):
             lr = 1e-5 if step < plateau_after else 1e-3
             opt.lr = lr
             i = (step * N) % 20
             x, y = images[i:i + N], labels[i:i + N]
             gpu.append(float(model.train_on_batch(x, y)))
+            gxy = np.asarray(model.loss_obj.terms.detach().cpu().numpy()[0], dtype=np.float64)
             for t, o in orc.items():
                 o.opt.lr = lr
                 ref[t].append(float(o.step(x, y)[0]))
+                oxy = o.loss.terms[0].double().numpy()
+                shift[t].append(float(np.abs(gxy - oxy).max() / abs(ref[t][-1])))
             if verbose:
                 print('step %2d lr %.0e  gpu %.4f  ' % (step + 1, lr, gpu[-1]) +
                       '  '.join('%s %.4f (rel %.2e)' % (t, v[-1], abs(gpu[-1] - v[-1]) / abs(v[-1])) for t, v in ref.items()), flush=True)
@@ -65,10 +73,19 @@ def run(steps=20, plateau_after=10, dtype='bfloat16', with_emulating_oracle=True
         backend.set_compute_dtype('bfloat16')
     out = {'config': 'ResNet18-YOLOv3 320x320, reference sample set (20 images), batch 2, 13 classes, lr 1e-5 for %d steps then 1e-3, %s GPU path'
                      % (min(plateau_after, steps), dtype), 'steps': steps, 'plateau_after': plateau_after, 'gpu_loss': gpu}
+    # "assignment": the loss assigns every ground truth to the (head, anchor) whose PREDICTED box fits it best -- a discrete choice.  When two
+    # candidates are within the trajectories' noise of each other, the GPU run and the oracle pick different ones for a step: the xy terms of two
+    # heads move by several per cent of the loss in opposite directions and the total jumps by ~1e-2 for that one step (tools/probes/
+    # loss_terms_ab.py shows such a step: xy of head 2 37.3 -> 24.2 between two summation orders of the SAME kernels' arithmetic).  Steps whose
+    # per-head xy terms differ by more than 5e-3 of the loss are listed as `assignment_differs`; the summary figures are given with and
+    # without them.
     for t, v in ref.items():
         rel = [abs(g - r) / abs(r) for g, r in zip(gpu, v)]
+        flagged = [k for k, sft in enumerate(shift[t]) if sft > 5e-3]
+        same = [r for k, r in enumerate(rel) if k not in flagged] or [0.0]
         out[t + '_oracle'] = {'loss': v, 'relative_deviation': rel, 'max': max(rel), 'median': float(np.median(rel)),
-                              'steps_within_1e-3': int(sum(r <= 1e-3 for r in rel))}
+                              'steps_within_1e-3': int(sum(r <= 1e-3 for r in rel)), 'xy_head_shift': shift[t],
+                              'assignment_differs': [k + 1 for k in flagged], 'max_same_assignment': max(same)}
     return out
 
 

@@ -12,8 +12,9 @@ import loss_curve
 
 SETTINGS = [('default', {}), ('wgrad9 off', {'wgrad9': 0}), ('wgrad9 64 wgs', {'wgrad9_wgs': 64}), ('wgrad9 96 wgs', {'wgrad9_wgs': 96}),
             ('wgrad9 192 wgs', {'wgrad9_wgs': 192}), ('wgrad9 256 wgs', {'wgrad9_wgs': 256}), ('s32 off', {'s32': 0}),
-            ('s32 off, wgrad9 off', {'s32': 0, 'wgrad9': 0}), ('wgrad strip off', {'wgrad9': 0, 'wgrad_strip': 0})]
-DEFAULTS = {'wgrad9': -1, 'wgrad9_wgs': 128, 's32': -1, 'wgrad_strip': 1}
+            ('s32 off, wgrad9 off', {'s32': 0, 'wgrad9': 0}), ('wgrad strip off', {'wgrad9': 0, 'wgrad_strip': 0}),
+            ('stride-2 classes on the implicit GEMM', {'s32_s2': 0})]
+DEFAULTS = {'wgrad9': -1, 'wgrad9_wgs': 128, 's32': -1, 'wgrad_strip': 1, 's32_s2': 1}
 
 
 def gpu_curve(dtype, weights, steps, plateau_after, tune=None):

@@ -1217,7 +1217,7 @@ int launch_fwd(const Gather& g, const void* w, const float* bias, void* y, int l
   int sbn = 0;
   if constexpr (!F32) {
     if (!bias && accumulate != 2 && yolo_stream_plan(g, Kout, false, nullptr)) return yolo_stream_launch(g, w, y, ldy, accumulate, e, Kout, st);
-    if (!bias && accumulate != 2 && s32_plan(g, Kout, false, nullptr)) return yolo_s32_launch(g, w, y, ldy, accumulate, e, Kout, st);
+    if (!bias && (accumulate != 2 || g.s2) && s32_plan(g, Kout, false, nullptr)) return yolo_s32_launch(g, w, y, ldy, accumulate, e, Kout, st);
   }
   if (const int sb = pick_strip(g, Kout, F32, &sbn)) {
     const bool wide = sbn == 128;
@@ -1247,6 +1247,7 @@ extern int g_bwd_fin_small;     // eltwise.hip
 extern int g_reduce_cap;        // eltwise.hip
 extern int g_fused_small_chunks;   // eltwise.hip
 extern int g_opt_wgs;              // optim.hip
+extern int g_s32_s2;               // conv_s32.hip
 
 extern "C" int yolo_set_tuning(const char* name, int value) {
   YOLO_CHECK_ARG(name != nullptr, "null name");
@@ -1272,6 +1273,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "rows_grid")) { YOLO_CHECK_ARG(value >= 64 && value <= 4096, "rows_grid"); g_rows_grid = value; }
   else if (!strcmp(name, "row_group")) { YOLO_CHECK_ARG(value == 0 || value == 8 || value == 16 || value == 32 || value == 64, "row_group"); g_row_group = value; }
   else if (!strcmp(name, "reduce_wgs")) { YOLO_CHECK_ARG(value == 0 || (value >= 16 && value <= 65536), "reduce_wgs"); g_reduce_wgs = value; }
+  else if (!strcmp(name, "s32_s2")) { YOLO_CHECK_ARG(value == 0 || value == 1, "s32_s2"); g_s32_s2 = value; }
   else if (!strcmp(name, "opt_wgs")) { YOLO_CHECK_ARG(value >= 16 && value <= 2048, "opt_wgs"); g_opt_wgs = value; }
   else if (!strcmp(name, "wgrad9_wgs")) { YOLO_CHECK_ARG(value >= 16 && value <= 1024, "wgrad9_wgs"); g_wgrad9_wgs = value; }
   else if (!strcmp(name, "wgrad9")) { YOLO_CHECK_ARG(value >= -1 && value <= 1, "wgrad9"); g_wgrad9 = value; }

@@ -42,6 +42,7 @@ struct S32Args {
   int H, W, C, M, Kg;                      // M = N*H*W, Kg = 9*C
   int E8;                                  // strip rows, multiple of 8 (>= BM + 2W + 2)
   float rhw, rw;
+  int OH, OW;                              // MODE 1: the output (dX) grid, 2H x 2W
 };
 
 typedef __attribute__((address_space(3))) bf16x8_t s32_lds_frag_t;
@@ -57,13 +58,22 @@ __device__ __forceinline__ int s32_select_bit(unsigned v, int bit, int a, int b)
   return d;
 }
 
-template <int WM, int WN, int WK, int PB, int CB, bool BNEPI>
+// MODE 1 = data gradient of a 3x3 / STRIDE-2 convolution (TF SAME on an even map: padding (0, 1)) as four parity classes of dX: class (ph, pw)
+// holds dX[2h' + ph][2w' + pw] = sum over the taps r = ph (mod 2), s = pw (mod 2) of dY[h' - (r >> 1)][w' - (s >> 1)] W[r][s] -- a stride-1
+// correlation over dY with the taps (dr, ds) in {-1, 0}^2 of which class (0,0) has 4, (0,1) and (1,0) 2, (1,1) 1 (9 in all: no multiply
+// by a structural zero).  Here `a.src` is dY on its own H x W grid (= the class grid), the channel tiles of the launch are (class, block)
+// pairs, a slice runs a fixed schedule of 4 K-step slots = the taps t in {0, 1, 3, 4} of the stride-1 numbering (so the address / mask
+// table below is the stride-1 one), a workgroup SKIPS the slots its class does not have (their weight pieces are requested out of range),
+// and the epilogue writes pixel (2h' + ph, 2w' + pw) of the OH x OW grid.  (reference: TF autodiff of the stride-2 Conv2D of
+// backbone/resnet18.py:29-32 via basic_backbone.py:20-43; implicit-GEMM counterpart: conv_igemm.hip, ClassView.)
+template <int WM, int WN, int WK, int PB, int CB, bool BNEPI, int MODE = 0>
 __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args a, void* __restrict__ Yv, int ldy, int accumulate,
                                                                        float* __restrict__ stat_sum, float* __restrict__ stat_sq, int Kout,
                                                                        int tiles_n, BnEpi bn) {
   constexpr int NW = WM * WN * WK, NT = NW * 64;
   constexpr int BM = WM * PB * 32, BN = WN * CB * 32;
-  constexpr int WS = 3;                          // weight ring stages (9 taps per slice: the stage of a tap is t % 3)
+  constexpr int NTAP = MODE ? 4 : 9;             // K-step slots per 64-channel slice
+  constexpr int WS = MODE ? 4 : 3;               // weight ring stages (NTAP is a multiple of WS: the stage of slot q is q % WS)
   constexpr int NS = 4 / WK;                     // k-substeps (16 channels each) of a tap that one wave computes
   constexpr int B_INSTR = BN / (8 * NW);         // weight LDS-DMA instructions per wave per tap (8 rows x 128 B each)
   constexpr int W_STAGE = BN * 128;
@@ -81,7 +91,20 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
   const int wk = wave % WK, wsp = wave / WK, wn = wsp % WN, wm = wsp / WN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nblk = MODE ? tiles_n >> 2 : tiles_n;                   // channel blocks per class
+  const int cls = MODE ? tile_n / nblk : 0, ph = cls >> 1, pw = cls & 1;
+  const int m0 = tile_m * BM, n0 = (MODE ? tile_n - cls * nblk : tile_n) * BN;
+  // MODE 1, per slot q = (dr, ds) in order (-1,-1) (-1,0) (0,-1) (0,0): does this class have it, and which tap of the flipped [Cin][9][Cout]
+  // weight tensor is it (kernel row r = ph ? 1 : (dr ? 2 : 0), flipped index 2 - r)
+  bool vq[4] = {true, true, true, true};
+  int wtq[4] = {0, 1, 3, 4};
+  if constexpr (MODE == 1) {
+    vq[0] = !ph && !pw; vq[1] = !ph; vq[2] = !pw;
+    const int fr_m = ph ? 1 : 0, fr_0 = ph ? 1 : 2, fs_m = pw ? 1 : 0, fs_0 = pw ? 1 : 2;      // flipped row / column of dr (ds) = -1 and 0
+    wtq[0] = 3 * fr_m + fs_m; wtq[1] = 3 * fr_m + fs_0; wtq[2] = 3 * fr_0 + fs_m; wtq[3] = 3 * fr_0 + fs_0;
+  }
+  auto wtap = [&](int q) { return MODE ? (q == 0 ? wtq[0] : (q == 1 ? wtq[1] : (q == 2 ? wtq[2] : wtq[3]))) : q; };      // (uniform selects)
+  auto wvalid = [&](int q) { return MODE ? (q == 0 ? vq[0] : (q == 1 ? vq[1] : (q == 2 ? vq[2] : true))) : true; };
   if (tid < 8) *reinterpret_cast<uint4*>(smem + zero0 + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
 
   // ---- LDS-DMA lane geometry: a piece is 8 rows x 128 bytes; lane -> row lane >> 3, 16-byte slot lane & 7, which holds chunk slot ^ sw(row)
@@ -103,10 +126,10 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
   }
 
   const int nchunk = a.C >> 6;
-  const int nk = nchunk * 9;
+  const int nk = nchunk * NTAP;
   auto issue_weights = [&](int cc, int tap, int stage) {
     char* sB = smem + ring0 + stage * W_STAGE + wave * (B_INSTR * 1024);
-    const unsigned koff = (unsigned)((tap * a.C + cc * 64) * 2);
+    const unsigned koff = (unsigned)((wtap(tap) * a.C + cc * 64) * 2) | (wvalid(tap) ? 0u : 0x80000000u);
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) buffer_load_lds16(a.wt, a.wt_bytes, sB + j * 1024, wbase[j] + koff);
   };
@@ -141,6 +164,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
     const unsigned ok = (unsigned)(((cb & r0) | (cb << 3) | ((cb << 6) & r2)) & ((m - a.M) >> 31));
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+      if (MODE == 1 && !(t == 0 || t == 1 || t == 3 || t == 4)) { tad[b][t] = 0; continue; }
       const int row = pl + (t / 3) * a.W + (t % 3);
       const int ad = row * 128 + (((2 * s0 + kh) ^ s32_sw(row)) << 4);
       tad[b][t] = s32_select_bit(ok, t, ad, zero0 + kh * 16);
@@ -173,9 +197,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
   bf16x8_t wf[CB][NS], pfa[PB][NS], pfb[PB][NS];
   int kk = 0;
   auto tap = [&](auto tc_, int cc, bf16x8_t (&cur)[PB][NS], bf16x8_t (&nxt)[PB][NS]) {
-    constexpr int t = decltype(tc_)::value;
-    constexpr int so = (t % 3) * W_STAGE;
-    constexpr int t2 = (t + 2) % 9, st2 = (t + 2) % 3;
+    constexpr int t = decltype(tc_)::value;                        // slot of the slice; its tap in the stride-1 numbering is GT(t)
+    constexpr int so = (t % WS) * W_STAGE;
+    constexpr int t2 = (t + 2) % NTAP, st2 = (t + 2) % WS;
     S32_T(ta);
     // weight stage kk (and, on the first tap of a slice, the strip) has landed; lgkmcnt(0): this wave's reads of the stage that is
     // refilled after this barrier have completed (an LDS-DMA write does not queue behind another wave's pending ds_read)
@@ -186,14 +210,28 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
     asm volatile("" ::: "memory");
     S32_T(tc);
     S32_T(td);
-    const unsigned koff = (unsigned)((t2 * a.C + (t + 2 >= 9 ? cc + 1 : cc) * 64) * 2);
-    const unsigned oob = kk + 2 < nk ? 0u : 0x80000000u;
+    const unsigned koff = (unsigned)((wtap(t2) * a.C + (t + 2 >= NTAP ? cc + 1 : cc) * 64) * 2);
+    const unsigned oob = (kk + 2 < nk && wvalid(t2)) ? 0u : 0x80000000u;
     char* const sB = smem + ring0 + st2 * W_STAGE + wave * (B_INSTR * 1024);
     if constexpr (t == 0) {
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int b = 0; b < PB; ++b) cur[b][s] = *reinterpret_cast<const s32_lds_frag_t*>(tad[b][0] ^ (s << 5));
+    }
+    if constexpr (MODE == 1) {
+      if (!wvalid(t)) {                                 // (uniform) this class does not have the slot: keep the schedule, skip the work
+        char* const sBs = smem + ring0 + st2 * W_STAGE + wave * (B_INSTR * 1024);
+#pragma unroll
+        for (int j = 0; j < B_INSTR; ++j) buffer_load_lds16(a.wt, a.wt_bytes, sBs + j * 1024, (wbase[j] + koff) | oob);
+        if constexpr (t < NTAP - 1) {
+          constexpr int tn_ = t + 1 < 2 ? t + 1 : t + 2;
+#pragma unroll
+          for (int r = 0; r < PB * NS; ++r) nxt[r % PB][r / PB] = *reinterpret_cast<const s32_lds_frag_t*>(tad[r % PB][tn_] ^ ((r / PB) << 5));
+        }
+        ++kk;
+        return;
+      }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -211,8 +249,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
       if (i % STEP == 0) {
         const int j = i / STEP;
         buffer_load_lds16(a.wt, a.wt_bytes, sB + j * 1024, (wbase[j] + koff) | oob);
-      } else if (t < 8) {
-        constexpr int tn = t < 8 ? t + 1 : 8;         // (t == 8: dead code, keeps the index in range for the compiler's bounds check)
+      } else if (t < NTAP - 1) {
+        constexpr int tq = t < NTAP - 1 ? t + 1 : NTAP - 1;      // (last slot: dead code, keeps the index in range for the compiler's bounds check)
+        constexpr int tn = MODE ? (tq < 2 ? tq : tq + 1) : tq;
         const int r = i - (i / STEP + 1);             // fragment reads issued in earlier slots
         if (r < PB * NS) nxt[r % PB][r / PB] = *reinterpret_cast<const s32_lds_frag_t*>(tad[r % PB][tn] ^ ((r / PB) << 5));
       }
@@ -238,11 +277,13 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
     tap(std::integral_constant<int, 1>{}, cc, pfb, pfa);
     tap(std::integral_constant<int, 2>{}, cc, pfa, pfb);
     tap(std::integral_constant<int, 3>{}, cc, pfb, pfa);
-    tap(std::integral_constant<int, 4>{}, cc, pfa, pfb);
-    tap(std::integral_constant<int, 5>{}, cc, pfb, pfa);
-    tap(std::integral_constant<int, 6>{}, cc, pfa, pfb);
-    tap(std::integral_constant<int, 7>{}, cc, pfb, pfa);
-    tap(std::integral_constant<int, 8>{}, cc, pfa, pfb);
+    if constexpr (MODE == 0) {
+      tap(std::integral_constant<int, 4>{}, cc, pfa, pfb);
+      tap(std::integral_constant<int, 5>{}, cc, pfb, pfa);
+      tap(std::integral_constant<int, 6>{}, cc, pfa, pfb);
+      tap(std::integral_constant<int, 7>{}, cc, pfb, pfa);
+      tap(std::integral_constant<int, 8>{}, cc, pfa, pfb);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the out-of-range pieces of the last two taps: nothing may be in flight into LDS below)
   S32_T(T2);
@@ -252,6 +293,8 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
   constexpr int CPR = BN / 8, RG = NT / CPR, ITER = (BM + RG - 1) / RG, NB = ITER <= 4 ? ITER : (ITER <= 8 ? 4 : (ITER + 1) / 2);
   static_assert(NT % CPR == 0, "row-walk geometry");
   const int e_ch = tid % CPR, e_rg = tid / CPR, e_c = n0 + e_ch * 8;
+  if constexpr (MODE == 1) accumulate = accumulate == 2 ? (cls == 0 ? 1 : 0) : accumulate;     // 2: only the even / even class has a previous contribution
+  const int prow = MODE ? cls * ((int)gridDim.x / tiles_n) + tile_m : tile_m;                  // partial row of the fused reduce: one per (class, pixel tile)
   bf16_t* const Y = reinterpret_cast<bf16_t*>(Yv);
   const bf16_t* const addp = bn.addend ? bn.addend : Y;
   constexpr int NBAT = (ITER + NB - 1) / NB;            // batches of NB rows per thread; the global reads of a batch are requested one batch ahead
@@ -266,7 +309,14 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
       const int row = e_rg + (it0 + k) * RG, m = m0 + row;
       e_off[set][k] = 0xffffffffu;                     // element offsets (the host refuses tensors of 2^31 elements or more)
       if (m < a.M && row < BM) {
-        e_off[set][k] = (unsigned)m * (unsigned)ldy + (unsigned)e_c;
+        int mo = m;
+        if constexpr (MODE == 1) {                     // pixel (2 y + ph, 2 x + pw) of the OH x OW grid
+          int n_, rem, y_, x_;
+          fast_divmod(m, a.H * a.W, a.rhw, n_, rem);
+          fast_divmod(rem, a.W, a.rw, y_, x_);
+          mo = (n_ * a.OH + 2 * y_ + ph) * a.OW + 2 * x_ + pw;
+        }
+        e_off[set][k] = (unsigned)mo * (unsigned)ldy + (unsigned)e_c;
         if constexpr (BNEPI) {
           e_yv[set][k] = *reinterpret_cast<const uint4*>(bn.y + e_off[set][k]);
           e_mk[set][k] = bn.mask ? (unsigned)bn.mask[e_off[set][k] >> 3] : 0xffu;
@@ -403,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void conv3x3_s32_kernel(S32Args 
       for (int r = 0; r < RG; ++r) t += red[r * BN + cl];
       if constexpr (BNEPI) {
         if (grouped) row_store(bn.partial + (rrow * 3 + q) * ldy + n0 + cl, t);
-        else if (bn.partial) bn.partial[((size_t)tile_m * 3 + q) * ldy + n0 + cl] = t;
+        else if (bn.partial) bn.partial[((size_t)prow * 3 + q) * ldy + n0 + cl] = t;
         else yolo_acc_add(bn.acc, 3, ldy, tile_m % YOLO_ACC_NB, q, n0 + cl, t);
       } else {
         if (grouped) row_store((q == 0 ? stat_sum : stat_sq) + rrow * Kout + n0 + cl, t);
@@ -436,14 +486,30 @@ constexpr S32Cfg kCfg[] = {
 };
 constexpr int kNCfg = (int)(sizeof(kCfg) / sizeof(kCfg[0]));
 
-size_t s32_lds(const S32Cfg& c, int W) {
+size_t s32_lds(const S32Cfg& c, int W, bool s2 = false) {
   const int bm = c.wm * c.pb * 32, bn = c.wn * c.cb * 32;
   const size_t e8 = (size_t)(bm + 2 * W + 2 + 7) / 8 * 8;
-  const size_t main_ = e8 * 128 + 3 * (size_t)bn * 128 + 128;
+  const size_t main_ = e8 * 128 + (s2 ? 4 : 3) * (size_t)bn * 128 + 128;
   const size_t out = (size_t)bm * (bn * 2 + 16);
   const size_t red = c.wk > 1 ? (size_t)c.wm * c.wn * (c.wk - 1) * c.pb * c.cb * 4096 : 0;
   size_t m = main_ > out ? main_ : out;
   return m > red ? m : red;
+}
+
+// the stride-2 data gradient as parity classes (dgrad_gather, conv_igemm.hip): 3x3, TF SAME on an even map (padding (0, 1): the class of even
+// rows / columns has the taps r = 2, 0 reading dY rows h' - 1, h'; the odd one the tap r = 1 reading row h'), every class H/2 x W/2
+bool s32_s2_eligible(const yoloconv::Gather& g, int Kout, bool f32) {
+  if (f32 || !g.s2 || g.s2_ny != 4 || g.S != 3 || g.RS != 9 || g.C0 != 0 || g.C1 % 64 != 0 || Kout % 64 != 0) return false;
+  if ((g.OH & 1) || (g.OW & 1) || g.Hs != g.OH / 2 || g.Ws != g.OW / 2) return false;
+  for (int d = 0; d < 2; ++d) {
+    const yoloconv::Gather::Dim* dm = d ? g.cold : g.rowd;
+    const int size = d ? g.OW / 2 : g.OH / 2;
+    if (dm[0].n != 2 || dm[0].pad != 1 || dm[0].t0 != 0 || dm[0].t1 != 2 || dm[0].size != size) return false;
+    if (dm[1].n != 1 || dm[1].pad != 0 || dm[1].t0 != 1 || dm[1].size != size) return false;
+  }
+  const size_t nimg = (size_t)g.N;
+  if (nimg * g.Hs * g.Ws * g.C1 * 2 >= (1ull << 31) || (size_t)Kout * g.Kg * 2 >= (1ull << 31) || nimg * g.OH * g.OW * Kout * 2 >= (1ull << 31)) return false;
+  return true;
 }
 
 bool s32_eligible(const yoloconv::Gather& g, int Kout, bool f32) {
@@ -454,36 +520,48 @@ bool s32_eligible(const yoloconv::Gather& g, int Kout, bool f32) {
   return true;
 }
 
-template <int WM, int WN, int WK, int PB, int CB, bool BNEPI>
+template <int WM, int WN, int WK, int PB, int CB, bool BNEPI, int MODE>
 int s32_launch_e(const yoloconv::Gather& g, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st) {
   constexpr int BM = WM * PB * 32, BN = WN * CB * 32, NT = WM * WN * WK * 64;
+  // MODE 1: the source is dY on its own grid (Hs x Ws = the class grid), g.M = pixels of one class, the output grid is OH x OW
+  const int H = MODE ? g.Hs : g.Ho, W = MODE ? g.Ws : g.Wo;
   S32Args a;
   a.src = g.src1;
   a.src_bytes = (unsigned)((size_t)g.M * g.C1 * 2);
   a.wt = (const bf16_t*)w;
   a.wt_bytes = (unsigned)((size_t)Kout * g.Kg * 2);
-  a.H = g.Ho; a.W = g.Wo; a.C = g.C1; a.M = g.M; a.Kg = g.Kg;
-  a.E8 = (BM + 2 * g.Wo + 2 + 7) / 8 * 8;
-  a.rhw = g.rhw; a.rw = g.rw;
+  a.H = H; a.W = W; a.C = g.C1; a.M = g.M; a.Kg = g.Kg;
+  a.E8 = (BM + 2 * W + 2 + 7) / 8 * 8;
+  a.rhw = 1.0f / (float)(H * W); a.rw = 1.0f / (float)W;
+  a.OH = g.OH; a.OW = g.OW;
   const S32Cfg c = {WM, WN, WK, PB, CB};
-  const size_t lds = s32_lds(c, g.Wo);
+  const size_t lds = s32_lds(c, W, MODE == 1);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s32_kernel<WM, WN, WK, PB, CB, BNEPI>),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_s32_kernel<WM, WN, WK, PB, CB, BNEPI, MODE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) { yolo_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(err)); return (int)err; }
     attr_set = true;
   }
-  const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
-  hipLaunchKernelGGL((conv3x3_s32_kernel<WM, WN, WK, PB, CB, BNEPI>), dim3(tiles_m * tn), dim3(NT), lds, st, a, y, ldy, accumulate, e.ssum, e.ssq,
-                     Kout, tn, e.bn);
+  const int tiles_m = (g.M + BM - 1) / BM, tn = (MODE ? 4 : 1) * (Kout / BN);
+  hipLaunchKernelGGL((conv3x3_s32_kernel<WM, WN, WK, PB, CB, BNEPI, MODE>), dim3(tiles_m * tn), dim3(NT), lds, st, a, y, ldy, accumulate, e.ssum,
+                     e.ssq, Kout, tn, e.bn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
 }
 template <int WM, int WN, int WK, int PB, int CB>
 int s32_launch_c(const yoloconv::Gather& g, const void* w, void* y, int ldy, int accumulate, const yoloconv::Epi& e, int Kout, hipStream_t st) {
-  if (e.bn.y) return s32_launch_e<WM, WN, WK, PB, CB, true>(g, w, y, ldy, accumulate, e, Kout, st);
-  return s32_launch_e<WM, WN, WK, PB, CB, false>(g, w, y, ldy, accumulate, e, Kout, st);
+  if (g.s2) {      // (the stride-2 classes: configurations 1 and 2 are instantiated)
+    if constexpr ((WM == 4 && WN == 1 && WK == 1) || (WM == 2 && WN == 1 && WK == 2)) {
+      if (e.bn.y) return s32_launch_e<WM, WN, WK, PB, CB, true, 1>(g, w, y, ldy, accumulate, e, Kout, st);
+      return s32_launch_e<WM, WN, WK, PB, CB, false, 1>(g, w, y, ldy, accumulate, e, Kout, st);
+    } else {
+      yolo_set_error("%s:%d: no stride-2 instantiation of this s32 configuration", __FILE__, __LINE__);
+      return YOLO_ERR_INVALID_ARG;
+    }
+  }
+  if (e.bn.y) return s32_launch_e<WM, WN, WK, PB, CB, true, 0>(g, w, y, ldy, accumulate, e, Kout, st);
+  return s32_launch_e<WM, WN, WK, PB, CB, false, 0>(g, w, y, ldy, accumulate, e, Kout, st);
 }
 
 }  // namespace
@@ -492,7 +570,20 @@ int s32_launch_c(const yoloconv::Gather& g, const void* w, void* y, int ldy, int
 int g_s32 = -1;
 
 // 0 = this kernel does not take the problem, else the pixel tile (statistics / partial rows = ceil(M / that))
+int g_s32_s2 = 1;       // "s32_s2" tuning: 1 = the stride-2 data gradient's parity classes on this kernel (default), 0 = on the implicit GEMM
+
 int yolo_s32_plan(const yoloconv::Gather& g, int Kout, bool f32, S32PlanOut* out) {
+  if (g.s2) {
+    // 256 x 64 tiles (one class-pixel tile x one 64-channel block of one class), 128 x 64 with a K split where that leaves the grid short
+    if (g_s32 == 0 || !g_s32_s2 || !s32_s2_eligible(g, Kout, f32)) return 0;
+    const int id = g.M >= 16384 ? 1 : 2;
+    const S32Cfg& c = kCfg[id];
+    const int bm = c.wm * c.pb * 32, bn = c.wn * c.cb * 32;
+    const size_t lds = s32_lds(c, g.Ws, true);
+    if (lds > 160 * 1024) return 0;
+    if (out) { out->id = id; out->bm = bm; out->bn = bn; out->tiles = (g.M + bm - 1) / bm * 4 * (Kout / bn); out->lds = lds; }
+    return bm;
+  }
   if (g_s32 == 0 || !s32_eligible(g, Kout, f32)) return 0;
   int id = -1;
   if (g_s32 > 0) id = g_s32 - 1;
