@@ -506,8 +506,10 @@ def main():
                                       'achieved': round(alone['stream']['rate'] / 1e12, 2), 'frac': round(alone['stream']['rate'] / 1e12 / PEAK_BF16_TFLOPS, 4),
                                       'in_step_achieved': round(instep['stream']['rate'] / 1e12, 2),
                                       'avg_launch_ms': round(alone['stream']['avg_launch_ms'], 5), 'launches_per_step': alone['stream']['launches_per_step']},
-                           'dgrad_bn': {'kernel': 'conv3x3_strip_kernel<.., true> / igemm_fwd_kernel<.., true>: data gradient + ReLU masking + BatchNorm-'
-                                                  'backward partial sums of the unit it completes (reads y and the sign bytes on top of the conv operands)',
+                           'dgrad_bn': {'kernel': 'conv3x3_strip_kernel<.., true> / conv3x3_s32_kernel<.., true> (strip_*: the 3x3 stride-1 layers); igemm_*: the other '
+                                                  'layers = the three 3x3 stride-2 ones as parity classes on conv3x3_s32_kernel<.., true, 1> + the 1x1 ones on '
+                                                  'igemm_fwd_kernel<.., true>: data gradient + ReLU masking + BatchNorm-backward partial sums of the unit it '
+                                                  'completes (reads y and the sign bytes on top of the conv operands)',
                                         'strip_achieved': round(alone['strip_bn']['rate'] / 1e12, 2),
                                         'strip_frac': round(alone['strip_bn']['rate'] / 1e12 / PEAK_BF16_TFLOPS, 4),
                                         'strip_in_step_achieved': round(instep['strip_bn']['rate'] / 1e12, 2),

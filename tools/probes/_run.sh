@@ -1,8 +1,10 @@
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-out=gpurun_out/r5y
+out=gpurun_out/r5z
 rm -rf $out && mkdir -p $out
-timeout -k 10 400 python -m pytest tests/test_s32_gpu.py -x -q > $out/test.log 2>&1; rc=$?; echo "pytest rc $rc" >> $out/test.log; tail -4 $out/test.log | cut -c1-200
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/test.log 2>&1; rc=$?; echo "pytest rc $rc" >> $out/test.log
+tail -4 $out/test.log
 [ $rc -eq 0 ] || exit 1
-timeout -k 10 200 python tools/probes/s2_dgrad_time.py 2>&1 | grep -v amdgpu.ids | tee $out/s2_fold.txt
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -2 $out/smoke.log
+bash tools/profile_round.sh r04_b > $out/profile_round.log 2>&1; tail -3 $out/profile_round.log
