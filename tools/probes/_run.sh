@@ -1,10 +1,6 @@
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-out=gpurun_out/r5z
+out=gpurun_out/r6c
 rm -rf $out && mkdir -p $out
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/test.log 2>&1; rc=$?; echo "pytest rc $rc" >> $out/test.log
-tail -4 $out/test.log
-[ $rc -eq 0 ] || exit 1
-timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -2 $out/smoke.log
-bash tools/profile_round.sh r04_b > $out/profile_round.log 2>&1; tail -3 $out/profile_round.log
+timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py tests/test_s32_gpu.py tests/test_train_step_gpu.py tests/test_configs_gpu.py tests/test_row_groups_gpu.py tests/test_stream_gpu.py -x -q > $out/test.log 2>&1; rc=$?; echo "pytest rc $rc" >> $out/test.log; tail -5 $out/test.log | cut -c1-200

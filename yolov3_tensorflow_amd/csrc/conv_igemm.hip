@@ -206,6 +206,7 @@ struct StripArgs {
   int H, W, C, M, Kg;                      // M = N*H*W, Kg = 9*C
   int E8;                                  // strip rows, multiple of 8 (>= BM + 2W + 2)
   float rhw, rw;
+  int xsplit;                              // 0: tiles dealt to the XCDs in contiguous runs; G = 2 / 4: XCD x takes channel-tile group x % G of pixel part x / G
 };
 
 template <int BM, int BN, int NW, int WS, bool BNEPI>
@@ -227,8 +228,21 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_strip_kernel(StripArgs a, con
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+  int tile_n, tile_m;
+  if (a.xsplit) {
+    // XCD-aware rectangle: with contiguous runs every XCD's L2 streams ALL weights and 1 / 8 of the pixels; here XCD x (= blockIdx & 7)
+    // owns the channel tiles of group x % G and the pixel tiles of part x / G: 1 / G of the weights, G / 8 of the pixels per L2.  The grid is
+    // padded to the largest part (workgroups past their part leave before any barrier).
+    const int G = a.xsplit, parts = 8 / G, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tiles_m = (a.M + BM - 1) / BM, nn = tiles_n / G;
+    const int mp = x / G, m_lo = mp * tiles_m / parts, m_hi = (mp + 1) * tiles_m / parts;
+    tile_n = (x % G) * nn + j % nn;
+    tile_m = m_lo + j / nn;
+    if (tile_m >= m_hi) return;
+  } else {
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    tile_n = tile % tiles_n; tile_m = tile / tiles_n;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (tid < 8) *reinterpret_cast<uint4*>(sZero + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
 
@@ -1059,6 +1073,10 @@ int g_wgrad_pipe = 1;    // "wgrad_pipe": software-pipelined stage body of the s
 int g_wgrad_ring = 2;    // "wgrad_ring": stages of the strip weight-gradient's operand ring (2 or 3)
 int g_wgrad_xcd = 1;     // "wgrad_xcd": 1 = 1-D weight-gradient grids with one contiguous run of logical blocks per XCD, 0 = plain 3-D grid
 int g_strip_ws = 0;      // "strip_ws": 0 auto, 2 / 3 force the weight-ring depth of the strip kernel
+// "strip_xsplit": 0 = contiguous tile runs per XCD, 2 (default) / 4 = XCD-aware rectangles in the strip kernel.  Alone the 13 x 13 / 26 x 26 launches
+// take the same time either way (they are not bound by their fetch); in the step, beside the weight-gradient stream, 2 gains +0.5 % (5 of 5
+// pairs, 8484 against 8444 images/s; 4: +0.2 %; profiles/r04_strip_xsplit_ab.txt) -- fewer weight bytes cross the fabric the two streams share
+int g_strip_xsplit = 2;
 // workgroups aimed at by the two-phase path: 1.5 per CU measured best on the whole step (256 / 384 / 512 tried: fewer slabs to sum
 // and less competition with the main stream's kernels outweigh the shorter pixel ranges of 512)
 int g_wgrad_target = 384;   // "wgrad_target" tuning
@@ -1137,7 +1155,14 @@ int launch_strip_ws_e(const Gather& g, const void* w, void* y, int ldy, int accu
     attr_set = true;
   }
   const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
-  hipLaunchKernelGGL((conv3x3_strip_kernel<BM, BN, NW, WS, BNEPI>), dim3(tiles_m * tn), dim3(NW * 64), lds, st, a, nullptr, y, ldy, accumulate, e.ssum, e.ssq,
+  int grid = tiles_m * tn;
+  a.xsplit = 0;
+  if (g_strip_xsplit && tn % g_strip_xsplit == 0 && tiles_m >= 8) {     // ("strip_xsplit" tuning: 0 off, 2 / 4 channel-tile groups)
+    const int G = g_strip_xsplit, parts = 8 / G;
+    a.xsplit = G;
+    grid = 8 * ((tiles_m + parts - 1) / parts) * (tn / G);
+  }
+  hipLaunchKernelGGL((conv3x3_strip_kernel<BM, BN, NW, WS, BNEPI>), dim3(grid), dim3(NW * 64), lds, st, a, nullptr, y, ldy, accumulate, e.ssum, e.ssq,
                      Kout, tn, e.bn);
   YOLO_LAUNCH_CHECK();
   return YOLO_OK;
@@ -1264,6 +1289,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "wgrad_pipe")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_pipe"); g_wgrad_pipe = value; }
   else if (!strcmp(name, "wgrad_ring")) { YOLO_CHECK_ARG(value == 2 || value == 3, "wgrad_ring"); g_wgrad_ring = value; }
   else if (!strcmp(name, "wgrad_xcd")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_xcd"); g_wgrad_xcd = value; }
+  else if (!strcmp(name, "strip_xsplit")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 4, "strip_xsplit"); g_strip_xsplit = value; }
   else if (!strcmp(name, "strip_ws")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 3, "strip_ws"); g_strip_ws = value; }
   else if (!strcmp(name, "ew_nt")) { YOLO_CHECK_ARG(value >= 0 && value <= 3, "ew_nt"); g_ew_nt = value; }
   else if (!strcmp(name, "acc_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "acc_stream_kelems"); g_acc_stream_elems = (int64_t)value * 1000; }
