@@ -99,7 +99,7 @@ int yolo_conv2d_fwd_plan(const yolo_conv_problem* p, int32_t* info8);
  * "s32": -1 (default) the automatic rule of the 32x32x16 strip kernel (conv_s32.hip: 3x3 stride-1 layers below 80 columns; it yields while "strip_bm" is not -1) / 0 never /
  * 1 + id force tile configuration id (0: 128 x 128, 1: 256 x 64, 2: 128 x 64 K split 2, 3: 64 x 128 K split 2, 4: 64 x 64 K split 4, 5: 256 x 128 on 8 waves, 6: 128 x 128 on 8 waves
  * K split 2, 7: 256 x 64 on 8 waves K split 2, 8: 384 x 128 on 8 waves with 96 x 64 wave tiles) where it fits (changes yolo_conv2d_stat_rows and yolo_conv2d_dgrad_bn_rows);
- * "strip_xsplit": 2 (default) / 4 / 0: the strip kernel deals its tiles to the XCDs as rectangles -- XCD x owns channel-tile group x % G of pixel part x / G, so an
+ * "strip_xsplit": -1 (default: 2 where the input is smaller than 4x the weights -- the 13 x 13 layers --, else 0) / 2 / 4 / 0: the strip kernel deals its tiles to the XCDs as rectangles -- XCD x owns channel-tile group x % G of pixel part x / G, so an
  * XCD's L2 sees 1 / G of the weights and G / 8 of the pixels -- or (0) as contiguous runs (all weights, 1 / 8 of the pixels per L2); same tiles, bit-identical results;
  * "s32_s2": 1 (default) the four parity classes of a 3x3 / stride-2 data gradient on an even map run on the 32x32x16 strip kernel (conv_s32.hip MODE 1:
  * four K-step slots per slice, a class skips the slots it does not have) / 0 on the implicit GEMM (changes yolo_conv2d_dgrad_bn_rows);

@@ -1,6 +1,11 @@
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-out=gpurun_out/r6c
+out=gpurun_out/r6e
 rm -rf $out && mkdir -p $out
-timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py tests/test_s32_gpu.py tests/test_train_step_gpu.py tests/test_configs_gpu.py tests/test_row_groups_gpu.py tests/test_stream_gpu.py -x -q > $out/test.log 2>&1; rc=$?; echo "pytest rc $rc" >> $out/test.log; tail -5 $out/test.log | cut -c1-200
+for i in 1 2 3 4; do
+  for t in 0 2 -1; do
+    YOLO_TUNE=strip_xsplit=$t timeout -k 10 200 python bench.py --steps 80 --warmup 10 --no-cpu-baseline --no-roofline > $out/b.json 2>$out/b.err || { echo FAILED; tail -5 $out/b.err; exit 1; }
+    python -c "import json; d=json.loads(open('$out/b.json').read().strip().splitlines()[-1]); print('strip_xsplit %-3s  %8.1f img/s  %.4f ms  loss %s' % ('$t', d['value'], d['ms_per_step'], d['config']['final_loss']))" | tee -a $out/ab.txt
+  done
+done

@@ -1073,10 +1073,11 @@ int g_wgrad_pipe = 1;    // "wgrad_pipe": software-pipelined stage body of the s
 int g_wgrad_ring = 2;    // "wgrad_ring": stages of the strip weight-gradient's operand ring (2 or 3)
 int g_wgrad_xcd = 1;     // "wgrad_xcd": 1 = 1-D weight-gradient grids with one contiguous run of logical blocks per XCD, 0 = plain 3-D grid
 int g_strip_ws = 0;      // "strip_ws": 0 auto, 2 / 3 force the weight-ring depth of the strip kernel
-// "strip_xsplit": 0 = contiguous tile runs per XCD, 2 (default) / 4 = XCD-aware rectangles in the strip kernel.  Alone the 13 x 13 / 26 x 26 launches
+// "strip_xsplit": 0 = contiguous tile runs per XCD, 2 / 4 = XCD-aware rectangles in the strip kernel, -1 (default) = 2 where that lowers the fetch
+// (launch_strip_ws_e).  Alone the 13 x 13 / 26 x 26 launches
 // take the same time either way (they are not bound by their fetch); in the step, beside the weight-gradient stream, 2 gains +0.5 % (5 of 5
 // pairs, 8484 against 8444 images/s; 4: +0.2 %; profiles/r04_strip_xsplit_ab.txt) -- fewer weight bytes cross the fabric the two streams share
-int g_strip_xsplit = 2;
+int g_strip_xsplit = -1;
 // workgroups aimed at by the two-phase path: 1.5 per CU measured best on the whole step (256 / 384 / 512 tried: fewer slabs to sum
 // and less competition with the main stream's kernels outweigh the shorter pixel ranges of 512)
 int g_wgrad_target = 384;   // "wgrad_target" tuning
@@ -1157,8 +1158,13 @@ int launch_strip_ws_e(const Gather& g, const void* w, void* y, int ldy, int accu
   const int tiles_m = (g.M + BM - 1) / BM, tn = Kout / BN;
   int grid = tiles_m * tn;
   a.xsplit = 0;
-  if (g_strip_xsplit && tn % g_strip_xsplit == 0 && tiles_m >= 8) {     // ("strip_xsplit" tuning: 0 off, 2 / 4 channel-tile groups)
-    const int G = g_strip_xsplit, parts = 8 / G;
+  // "strip_xsplit": -1 (default) = 2 x 4 rectangles where they lower the bytes the eight L2s fetch together -- 8 W / G + X G for weights W and
+  // input X, against 8 W + X for contiguous runs: G = 2 wins iff X < 4 W (the 13 x 13 layers: 5.5 MB of pixels, 2.4-4.7 MB of weights; not the
+  // 26 x 26 ones: 11 MB against 1.2-2.4) --, 0 never, 2 / 4 always
+  int G = g_strip_xsplit;
+  if (G < 0) G = (size_t)g.M * g.C1 < 4 * (size_t)Kout * g.Kg ? 2 : 0;
+  if (G && tn % G == 0 && tiles_m >= 8) {
+    const int parts = 8 / G;
     a.xsplit = G;
     grid = 8 * ((tiles_m + parts - 1) / parts) * (tn / G);
   }
@@ -1289,7 +1295,7 @@ extern "C" int yolo_set_tuning(const char* name, int value) {
   else if (!strcmp(name, "wgrad_pipe")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_pipe"); g_wgrad_pipe = value; }
   else if (!strcmp(name, "wgrad_ring")) { YOLO_CHECK_ARG(value == 2 || value == 3, "wgrad_ring"); g_wgrad_ring = value; }
   else if (!strcmp(name, "wgrad_xcd")) { YOLO_CHECK_ARG(value == 0 || value == 1, "wgrad_xcd"); g_wgrad_xcd = value; }
-  else if (!strcmp(name, "strip_xsplit")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 4, "strip_xsplit"); g_strip_xsplit = value; }
+  else if (!strcmp(name, "strip_xsplit")) { YOLO_CHECK_ARG(value == -1 || value == 0 || value == 2 || value == 4, "strip_xsplit"); g_strip_xsplit = value; }
   else if (!strcmp(name, "strip_ws")) { YOLO_CHECK_ARG(value == 0 || value == 2 || value == 3, "strip_ws"); g_strip_ws = value; }
   else if (!strcmp(name, "ew_nt")) { YOLO_CHECK_ARG(value >= 0 && value <= 3, "ew_nt"); g_ew_nt = value; }
   else if (!strcmp(name, "acc_stream_kelems")) { YOLO_CHECK_ARG(value >= 0, "acc_stream_kelems"); g_acc_stream_elems = (int64_t)value * 1000; }
