@@ -1,10 +1,11 @@
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-out=gpurun_out/r6f
+out=gpurun_out/r6g
 rm -rf $out && mkdir -p $out
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $out/test.log 2>&1; rc=$?; echo "pytest rc $rc" >> $out/test.log
-tail -4 $out/test.log
-[ $rc -eq 0 ] || exit 1
-timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -2 $out/smoke.log
-bash tools/profile_round.sh r04_e > $out/profile_round.log 2>&1; tail -2 $out/profile_round.log
+for i in 1 2 3; do
+  for t in "wgrad9=-1" "wgrad9=1"; do
+    YOLO_TUNE=$t timeout -k 10 200 python bench.py --steps 80 --warmup 10 --no-cpu-baseline --no-roofline > $out/b.json 2>$out/b.err || { echo FAILED; tail -5 $out/b.err; exit 1; }
+    python -c "import json; d=json.loads(open('$out/b.json').read().strip().splitlines()[-1]); print('%-12s  %8.1f img/s  %.4f ms  loss %s' % ('$t', d['value'], d['ms_per_step'], d['config']['final_loss']))" | tee -a $out/ab.txt
+  done
+done
